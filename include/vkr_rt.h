@@ -1,0 +1,251 @@
+/*
+ * vkr_rt.h -- C ABI of the MI355X-native RTAO / shadow-ray path.
+ *
+ * This is the drop-in boundary for ONE hot path of chenjunjia-java/VulkanRenderer:
+ *   RtaoComputePass (trace+temporal -> A-Trous xN -> upsample) + the pbr.frag shadow rays,
+ *   with the Vulkan TLAS/BLAS + rayQueryEXT replaced by a HIP LBVH.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository root).  The reference-side binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures: a stream is passed as `void*`
+ *     (a hipStream_t; NULL = the default stream).  Work is enqueued asynchronously on that
+ *     stream, like commands recorded into the reference's single command buffer
+ *     (Renderer.cpp:330-359); vkr_sync() is the fence.
+ *   - every function returns a vkr_status (0 = OK) and never throws; the reference throws
+ *     std::runtime_error (RayTracingContext.cpp:49-53,59,77; Rendergraph.cpp:95,120) -- the C++
+ *     adapter (include/vkr_pass.hpp) turns a non-zero status back into std::runtime_error.
+ *   - a context is NOT thread-safe (reference: single render thread, VulkanApplication.cpp:56-69).
+ *   - images are tightly packed row-major arrays in DEVICE memory:
+ *       R16F    -> uint16_t[W*H]      (IEEE binary16 bits)
+ *       RGBA16F -> uint16_t[W*H*4]
+ *   - "host" pointers are read during the call and may be freed when it returns.
+ */
+#ifndef VKR_RT_H
+#define VKR_RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define VKR_API
+#else
+#define VKR_API __attribute__((visibility("default")))
+#endif
+
+typedef enum vkr_status {
+    VKR_OK = 0,
+    VKR_ERR_INVALID_ARG = 1, /* null pointer, bad size, count mismatch            */
+    VKR_ERR_STATE = 2,       /* call order (e.g. trace before bvh_build)          */
+    VKR_ERR_HIP = 3,         /* a HIP runtime call failed; see vkr_last_error()   */
+    VKR_ERR_OOM = 4,         /* device allocation failed                          */
+    VKR_ERR_LIMIT = 5        /* a fixed capacity was exceeded (stack depth, ...)  */
+} vkr_status;
+
+typedef struct vkr_ctx vkr_ctx;
+
+/* AppConfig::MAX_REFLECTION_MATERIAL_COUNT (rtao_trace_half.comp:44, FrameManager.cpp:1355-1357). */
+#define VKR_MAX_MATERIALS 256u
+/* Floats in PBRUniformBufferObject (VulkanTypes.h:47-62): 3 mat4 + 11 vec4 + 1 mat4 = 480 B. */
+#define VKR_UBO_FLOATS 120u
+
+/* Offsets (in floats) of the UBO fields the path reads -- layout of VulkanTypes.h:47-62. */
+enum {
+    VKR_UBO_MODEL = 0,
+    VKR_UBO_VIEW = 16,
+    VKR_UBO_PROJ = 32,
+    VKR_UBO_DIR_LIGHT_DIR = 48,
+    VKR_UBO_DIR_LIGHT_COLOR = 52,
+    VKR_UBO_DIR_LIGHT_PARAMS = 56, /* x = sun angular radius (rad), y = soft shadow sample count */
+    VKR_UBO_LIGHT_POSITIONS = 60,  /* 3 x vec4 */
+    VKR_UBO_LIGHT_COLORS = 72,     /* 3 x vec4 */
+    VKR_UBO_CAM_POS = 84,
+    VKR_UBO_PARAMS = 88,      /* w = pointLightCount */
+    VKR_UBO_IBL_PARAMS = 92,  /* w = debug view mode (9..12 change RTAO outputs) */
+    VKR_UBO_RTAO_PARAMS0 = 96,  /* x enable, y rayCount, z radius, w bias */
+    VKR_UBO_RTAO_PARAMS1 = 100, /* x strength, y temporalAlpha, z disocclusionThreshold, w frameIndex */
+    VKR_UBO_PREV_VIEW_PROJ = 104
+};
+
+/* ---------------------------------------------------------------- context -------------- */
+
+typedef struct vkr_create_desc {
+    int32_t device;   /* HIP device ordinal                                              */
+    uint32_t width;   /* swapchain extent: all RTAO images are full resolution          */
+    uint32_t height;  /*   (FrameManager.cpp:996-1002, RtaoComputePass.cpp:505-507)     */
+} vkr_create_desc;
+
+/* Replaces: construction of RtaoComputePass + RtaoComputePipeline + the RTAO slice of FrameManager
+ * (RtaoComputePass.cpp:16-25, RtaoComputePipeline.cpp:30-75, FrameManager::createRtaoComputeTextures
+ * FrameManager.cpp:989-1092).  Allocates history x2, ping-pong x2 (R16F, cleared to 1.0 like
+ * FrameManager.cpp:1057) and frame index 0. */
+VKR_API int vkr_create(const vkr_create_desc* desc, vkr_ctx** out);
+/* Replaces: Renderer::cleanup release order (Renderer.cpp:224-253). Safe on NULL. */
+VKR_API void vkr_destroy(vkr_ctx* ctx);
+/* Text of the last failure on this context ("" if none). With ctx == NULL: the last vkr_create failure. */
+VKR_API const char* vkr_last_error(const vkr_ctx* ctx);
+/* The fence: hipStreamSynchronize(stream) (reference: waitForFences, Renderer.cpp:265-266). */
+VKR_API int vkr_sync(vkr_ctx* ctx, void* stream);
+
+/* ---------------------------------------------------------------- scene ---------------- */
+
+/* One reference Mesh (= one glTF primitive, GltfModelLoader.cpp:630-717).  HOST pointers. */
+typedef struct vkr_mesh_desc {
+    const void* positions;     /* float3 at offset 0 of each vertex (Vertex.h: pos first)        */
+    uint32_t position_stride;  /* bytes between vertices; 60 = sizeof(Vertex), RayTracingContext.cpp:213-219 */
+    uint32_t vertex_count;
+    const uint32_t* indices;   /* mesh-local vertex ids; primitiveCount = index_count/3 (RayTracingContext.cpp:230) */
+    uint32_t index_count;
+    const void* uvs;           /* float2 texCoord per vertex (V already flipped, GltfModelLoader.cpp:649); may be NULL */
+    uint32_t uv_stride;        /* bytes between texCoords                                         */
+    int32_t material_index;    /* Mesh::materialIndex; out of range => opaque, LUT material 0
+                                  (Renderer.cpp:83-86, FrameManager.cpp:1280-1283)                */
+    uint32_t opaque;           /* meshOpaqueFlags[i] (Renderer.cpp:80-87): BLAS geometry eOpaque flag
+                                  (RayTracingContext.cpp:226-227)                                 */
+} vkr_mesh_desc;
+
+/* RayTracingInstanceDesc (RayTracingContext.h:10-13) after toVkTransformMatrix (RayTracingContext.cpp:28-44):
+ * 3x4 ROW-major world-from-mesh; customIndex = mesh_index, mask 0xFF, cull disabled (:62-68). */
+typedef struct vkr_instance {
+    uint32_t mesh_index;
+    float transform[12];
+} vkr_instance;
+
+/* LOD-0 alpha plane of material m's baseColor texture (rtao_trace_half.comp:170 reads .a only). */
+typedef struct vkr_alpha_texture {
+    const uint8_t* alpha; /* HOST, width*height unorm8, row 0 = v 0; NULL => alpha 1.0 everywhere */
+    uint32_t width;
+    uint32_t height;
+} vkr_alpha_texture;
+
+typedef struct vkr_scene_desc {
+    const vkr_mesh_desc* meshes;
+    uint32_t mesh_count;
+    const vkr_instance* instances;   /* DFS order of Renderer::rebuildRayTracingInstances (Renderer.cpp:503-527) */
+    uint32_t instance_count;
+    /* materialParams[256] vec4: x = alphaCutoff, y = alphaMode 0/1/2 (FrameManager.cpp:1354-1371). HOST, 1024 floats. */
+    const float* material_params;
+    /* baseColorArray[256] (rtao_trace_half.comp:45). HOST array of VKR_MAX_MATERIALS entries, or NULL. */
+    const vkr_alpha_texture* alpha_textures;
+} vkr_scene_desc;
+
+/* Replaces: RayTracingContext::init inputs (RayTracingContext.cpp:124-137) + FrameManager::createReflectionBuffers
+ * (FrameManager.cpp:1229-1381): uploads vertices/indices, builds InstanceLUT {materialID, indexBufferOffset},
+ * merged global-id index buffer, merged UV buffer, materialParams, alpha planes. Synchronous. */
+VKR_API int vkr_scene_upload(vkr_ctx* ctx, const vkr_scene_desc* scene);
+
+/* Replaces: buildBottomLevelASes + buildTopLevelAS + buildOrUpdateTopLevelAS(eBuild)
+ * (RayTracingContext.cpp:199-345,110-122).  Flattens instances to world-space triangles, Morton codes,
+ * LDS radix sort, Karras hierarchy, bottom-up AABB fit.  Empty meshes are skipped (:206-208,231-233). */
+VKR_API int vkr_bvh_build(vkr_ctx* ctx, void* stream);
+
+/* Replaces: RayTracingContext::updateTopLevelAS (RayTracingContext.cpp:165-197): same topology, new
+ * transforms -> re-transform triangles + refit.  `count` must equal the build-time instance count and
+ * mesh indices must be unchanged, else VKR_ERR_INVALID_ARG (reference throws "instance count mismatch", :51-53). */
+VKR_API int vkr_bvh_refit(vkr_ctx* ctx, const vkr_instance* instances, uint32_t count, void* stream);
+
+typedef struct vkr_bvh_info {
+    uint32_t triangle_count; /* flattened world-space triangles = leaves            */
+    uint32_t node_count;     /* internal nodes (triangle_count - 1, or 0)           */
+    uint32_t height;         /* longest root->leaf path, in internal nodes          */
+    uint32_t morton_bits;    /* bits per axis used by the last build (21 or 10)     */
+    float bounds_min[3];
+    float bounds_max[3];
+} vkr_bvh_info;
+/* Synchronises the build stream. No reference counterpart (driver-internal AS is opaque). */
+VKR_API int vkr_bvh_info_get(vkr_ctx* ctx, vkr_bvh_info* out);
+
+/* Debug/inspection copies of the BVH to HOST memory for structural tests (no reference counterpart:
+ * the Vulkan AS is opaque).  nodes: node_count x 16 floats
+ * {lmin xyz, lmax xyz, rmin xyz, rmax xyz, left(bits), right(bits), 0, 0}; child < 0 => leaf ~child.
+ * tris: triangle_count x 12 floats {v0 xyz, mesh(bits), e1 xyz, prim(bits), e2 xyz, flags(bits)}. */
+VKR_API int vkr_bvh_download(vkr_ctx* ctx, float* nodes, float* tris);
+
+/* ---------------------------------------------------------------- RTAO pass ------------- */
+
+/* Arguments of one RtaoComputePass::execute = the descriptor set of RtaoComputePipeline.cpp:34-53.
+ * Device pointers unless stated.  Binding 1 (HW depth) is bound but never sampled by the shaders: dropped. */
+typedef struct vkr_rtao_frame_io {
+    float ubo[VKR_UBO_FLOATS];         /* binding 0: PBRUniformBufferObject verbatim (HOST values)          */
+    uint32_t atrous_iterations;        /* max(1, denoise ? RTAO_ATROUS_ITERATIONS : 1), RtaoComputePass.cpp:529 */
+    const uint16_t* linear_depth_r16f; /* binding 17: linearDepthResolve, 0 = sky (DepthPrepass.cpp:48)      */
+    const uint16_t* normal_rgba16f;    /* binding 2: normalResolve, n*0.5+0.5 (depth_only.frag:31-33)         */
+    uint16_t* rtao_full_r16f;          /* binding 10: rtaoFull output (FrameManager.cpp:1089-1091)            */
+    uint32_t* ray_hit_mask;            /* optional debug tap (may be NULL): bit i = AO ray i ended occluded   */
+} vkr_rtao_frame_io;
+
+/* Replaces: RtaoComputePass::render (RtaoComputePass.cpp:102-156): dispatchTrace -> dispatchAtrous (N) ->
+ * dispatchUpsample, then flips the history ping-pong index like FrameManager.cpp:1155-1165.
+ * UBO semantics are the caller's, exactly as in the reference (FrameManager.cpp:448-462,501-510):
+ * prevViewProj = last frame's proj*view, rtaoParams1.w = frames since (re)create. */
+VKR_API int vkr_rtao_execute(vkr_ctx* ctx, const vkr_rtao_frame_io* io, void* stream);
+
+/* Row-band variant for multi-GPU (no reference counterpart: the reference is single-GPU).  Produces rows
+ * [y0, y1) of rtao_full and of history[curr]; rows outside are untouched.  Internally traces and filters the
+ * A-Trous halo (2*(2^N - 1) rows each side) so the band is bit-identical to the same rows of a full-frame
+ * vkr_rtao_execute.  The caller all-gathers the bands (history via vkr_rtao_history) before the next frame. */
+VKR_API int vkr_rtao_execute_band(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t y0, uint32_t y1, void* stream);
+
+/* The three dispatches, individually callable (RtaoComputePass.cpp:503-517, 519-554, 556-571).
+ * Push constants {width,height,step,iteration} (RtaoComputePass.h:21-26) become arguments. */
+VKR_API int vkr_rtao_trace(vkr_ctx* ctx, const vkr_rtao_frame_io* io, void* stream);
+VKR_API int vkr_rtao_atrous(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t step, uint32_t iteration, void* stream);
+VKR_API int vkr_rtao_upsample(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t final_index, void* stream);
+/* Advance the frame-in-flight index (history curr/prev swap), FrameManager.cpp:1155-1165. vkr_rtao_execute
+ * calls this itself; callers of the three separate dispatches call it once per frame. */
+VKR_API int vkr_rtao_end_frame(vkr_ctx* ctx);
+
+/* Replaces: swapchain-recreate reset (FrameManager.cpp:28,57-58,1057): frame-in-flight index 0, history and
+ * ping-pong cleared to 1.0. */
+VKR_API int vkr_rtao_reset(vkr_ctx* ctx, void* stream);
+
+/* Context-owned images (device pointers, R16F W*H): which = 0 history[curr of the LAST executed frame],
+ * 1 history[prev], 2 ping0, 3 ping1.  Reference: FrameManager getters used at RtaoComputePass.cpp:289-368. */
+VKR_API int vkr_rtao_image(vkr_ctx* ctx, uint32_t which, uint16_t** out);
+
+/* ---------------------------------------------------------------- shadow rays ----------- */
+
+/* pbr.frag lifted from per-fragment to per-pixel.  world_pos / geom_normal: float3 per pixel (device),
+ * valid: optional uint8 per pixel (0 => pixel skipped, output 1.0), out_vis: float per pixel (device). */
+
+/* Replaces: ComputeShadowVisibilityDirectional (pbr.frag:217-260) with L = -normalize(directionalLightDir.xyz)
+ * (pbr.frag:379-380) taken from `light_dir_to_light` (already negated+normalised by the caller),
+ * sun_radius / samples = directionalLightParams.xy. */
+VKR_API int vkr_shadow_sun(vkr_ctx* ctx, const float* world_pos, const float* geom_normal, const uint8_t* valid,
+                           uint32_t pixel_count, const float light_dir_to_light[3], float sun_radius,
+                           float sample_count, float* out_vis, void* stream);
+/* Replaces: ComputeShadowVisibility (pbr.frag:169-196), one light. */
+VKR_API int vkr_shadow_point(vkr_ctx* ctx, const float* world_pos, const float* geom_normal, const uint8_t* valid,
+                             uint32_t pixel_count, const float light_pos[3], float* out_vis, void* stream);
+
+/* ---------------------------------------------------------------- G-buffer producer ----- */
+
+/* SURVEY 8(f) row 2 (input side of the path): stands in for DepthPrepass (depth_prepass.vert:42-52,
+ * depth_only.frag:20-35) by casting one primary ray per pixel centre through the same BVH.
+ * Outputs (device, any may be NULL): linear view-Z R16F (0 = sky), normal*0.5+0.5 RGBA16F
+ * (clear value (0.5,0.5,1,1), DepthPrepass.cpp:36), world position float3, geometric normal float3
+ * (flipped to face the camera, pbr.frag:339-346), valid uint8. */
+VKR_API int vkr_gbuffer_primary(vkr_ctx* ctx, const float ubo[VKR_UBO_FLOATS], uint16_t* linear_depth_r16f,
+                                uint16_t* normal_rgba16f, float* world_pos, float* geom_normal, uint8_t* valid,
+                                void* stream);
+
+/* ---------------------------------------------------------------- counters -------------- */
+
+typedef struct vkr_trace_stats {
+    uint64_t rays;          /* ray queries issued (AO rays + retries)      */
+    uint64_t nodes_visited; /* internal nodes popped                        */
+    uint64_t tris_tested;   /* ray/triangle tests                           */
+} vkr_trace_stats;
+/* Enable (1) / disable (0) traversal counters for subsequent AO traces (slower kernel variant), and read
+ * them back (synchronises).  Feeds bench.py's algorithmic-bytes figure. */
+VKR_API int vkr_trace_stats_enable(vkr_ctx* ctx, int enable);
+VKR_API int vkr_trace_stats_get(vkr_ctx* ctx, vkr_trace_stats* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKR_RT_H */

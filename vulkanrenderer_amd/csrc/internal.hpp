@@ -1,0 +1,151 @@
+// internal.hpp -- host-side context and launcher declarations shared by the translation units of libvkr_rt.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vkr_rt.h"
+#include "traverse.hpp"
+
+namespace vkr {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        else p = nullptr;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// Per-frame constants of the RTAO kernels: PBRUniformBufferObject fields + host-hoisted inverses
+// (rtao_trace_half.comp:245-246 computes inverse(proj)/inverse(view) per thread).
+struct FrameParams {
+    float invProj[16];
+    float invView[16];
+    float view[16];
+    float prevViewProj[16];
+    float camPos[3];
+    uint32_t debugMode;
+    int rayCount;
+    float baseRadius;   // max(rtaoParams0.z, 0.01)
+    float baseBias;     // max(rtaoParams0.w, 0.0005)
+    float frameIndex;   // rtaoParams1.w
+    float temporalAlphaRaw;  // rtaoParams1.y
+    float disocclusionRaw;   // rtaoParams1.z
+    float radiusRaw;         // rtaoParams0.z (A-Trous uses max(.,0.01) itself)
+    int W, H;
+};
+
+// inverse of the ordered-uint float encoding used for atomicMin/atomicMax on bounds
+__host__ __device__ inline float dec_f(uint32_t u)
+{
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, b);
+}
+
+struct BvhBounds {  // ordered-uint encoded floats, updated with atomicMin/atomicMax
+    uint32_t tri_min[3], tri_max[3], cen_min[3], cen_max[3];
+};
+
+}  // namespace vkr
+
+struct vkr_ctx {
+    int device = 0;
+    uint32_t W = 0, H = 0;
+    std::string err;
+
+    // ---- scene (FrameManager::createReflectionBuffers + RayTracingContext inputs)
+    bool has_scene = false;
+    uint32_t mesh_count = 0, instance_count = 0, tri_count = 0;
+    std::vector<uint32_t> h_inst_mesh;       // mesh index per instance (refit validation)
+    std::vector<uint32_t> h_mesh_prims;      // primitives per mesh
+    vkr::DevBuf<float> d_positions;          // merged xyz
+    vkr::DevBuf<uint32_t> d_indices;         // merged, global vertex ids (FrameManager.cpp:1296-1304)
+    vkr::DevBuf<float2> d_uvs;               // merged (FrameManager.cpp:1287-1294)
+    vkr::DevBuf<uint2> d_lut;                // InstanceLUTEntry (FrameManager.cpp:1276-1285)
+    vkr::DevBuf<uint32_t> d_mesh_class;      // per mesh AO class (0 commit, 1 skip, 2 alpha test)
+    vkr::DevBuf<float4> d_material_params;   // 256 x vec4 (FrameManager.cpp:1354-1371)
+    vkr::DevBuf<vkr::AlphaTexDev> d_alpha_tex;
+    vkr::DevBuf<uint8_t> d_alpha_data;
+    vkr::DevBuf<uint32_t> d_inst_mesh;
+    vkr::DevBuf<uint32_t> d_inst_first_tri;  // exclusive prefix of primitives per instance (+1 entry)
+    vkr::DevBuf<float> d_inst_xf;            // 12 floats per instance
+
+    // ---- BVH
+    bool has_bvh = false;
+    uint32_t morton_bits = 21;
+    uint32_t bvh_height = 0;
+    vkr::DevBuf<float4> d_nodes;             // 4 x float4 per internal node
+    vkr::DevBuf<float4> d_tris;              // 3 x float4 per leaf, Morton order
+    vkr::DevBuf<uint32_t> d_perm;            // sorted position -> flat triangle id
+    vkr::DevBuf<uint32_t> d_leaf_parent, d_node_parent, d_flags;
+    vkr::DevBuf<uint64_t> d_keys[2];
+    vkr::DevBuf<uint32_t> d_vals[2];
+    vkr::DevBuf<uint32_t> d_hist, d_digit_totals;
+    vkr::DevBuf<vkr::BvhBounds> d_bounds;
+    vkr::DevBuf<uint32_t> d_height;
+    float bounds_min[3] = {0, 0, 0}, bounds_max[3] = {0, 0, 0};
+    void* build_stream = nullptr;
+
+    // ---- RTAO images (FrameManager::createRtaoComputeTextures)
+    vkr::DevBuf<uint16_t> d_hist_img[2], d_ping[2];
+    vkr::DevBuf<float4> d_nz;                // per-frame decoded normal.xyz + clamped depth (A-Trous operand)
+    uint32_t frame_parity = 0;               // FrameManager currentFrame % 2
+    uint32_t last_curr = 0;
+
+    // ---- counters
+    bool stats_enabled = false;
+    vkr::DevBuf<unsigned long long> d_stats; // rays, nodes, tris
+};
+
+namespace vkr {
+
+inline SceneDev scene_dev(const vkr_ctx* c)
+{
+    SceneDev s;
+    s.nodes = c->d_nodes.p;
+    s.tris = c->d_tris.p;
+    s.tri_count = c->has_bvh ? c->tri_count : 0;
+    s.lut = c->d_lut.p;
+    s.indices = c->d_indices.p;
+    s.uvs = c->d_uvs.p;
+    s.material_params = c->d_material_params.p;
+    s.alpha_tex = c->d_alpha_tex.p;
+    s.alpha_data = c->d_alpha_data.p;
+    return s;
+}
+
+// bvh_build.hip
+hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st);
+// rtao_kernels.hip
+hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,
+                             uint16_t* hist_curr, uint32_t* hit_mask, int y0, int y1, hipStream_t st);
+hipError_t rtao_prep_launch(vkr_ctx* c, const uint16_t* depth, const uint16_t* normal, int y0, int y1, hipStream_t st);
+hipError_t rtao_atrous_launch(vkr_ctx* c, float radius_raw, int step, const uint16_t* src, uint16_t* dst,
+                              uint16_t* dst2, int y0, int y1, hipStream_t st);
+hipError_t rtao_upsample_launch(vkr_ctx* c, uint32_t debug_mode, const uint16_t* src, const uint16_t* normal,
+                                uint16_t* dst, int y0, int y1, hipStream_t st);
+hipError_t fill_r16f_launch(uint16_t* img, size_t count, float value, hipStream_t st);
+// shadow_kernels.hip
+hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
+                             const float L[3], float radius, float samples, float* out, hipStream_t st);
+hipError_t shadow_point_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
+                               const float P[3], float* out, hipStream_t st);
+hipError_t gbuffer_launch(vkr_ctx* c, const FrameParams& fp, uint16_t* depth, uint16_t* normal, float* wp, float* ng,
+                          uint8_t* valid, hipStream_t st);
+
+}  // namespace vkr

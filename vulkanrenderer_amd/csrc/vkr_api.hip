@@ -1,0 +1,559 @@
+// vkr_api.hip -- the C ABI of include/vkr_rt.h: context, scene upload, BVH build/refit, the RtaoComputePass
+// dispatch sequence and the shadow/G-buffer entry points.  Host code only; kernels live in the other files.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "internal.hpp"
+
+using namespace vkr;
+
+namespace {
+
+std::string g_create_error;
+
+int fail(vkr_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_OR_FAIL(c, call)                                                                        \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail((c), e_ == hipErrorOutOfMemory ? VKR_ERR_OOM : VKR_ERR_HIP, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                                     \
+    } while (0)
+
+// inverse(mat4) hoisted from the shader (rtao_trace_half.comp:245-246): cofactors in double, one rounding.
+void inverse_m4(const float* mf, float* out)
+{
+    double m[16], inv[16];
+    for (int i = 0; i < 16; ++i) m[i] = (double)mf[i];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    double id = 1.0 / det;
+    for (int i = 0; i < 16; ++i) out[i] = (float)(inv[i] * id);
+}
+
+inline float gmax_h(float a, float b) { return (a < b) ? b : a; }
+
+FrameParams make_frame_params(const vkr_ctx* c, const float* ubo)
+{
+    FrameParams fp;
+    inverse_m4(ubo + VKR_UBO_PROJ, fp.invProj);
+    inverse_m4(ubo + VKR_UBO_VIEW, fp.invView);
+    memcpy(fp.view, ubo + VKR_UBO_VIEW, 64);
+    memcpy(fp.prevViewProj, ubo + VKR_UBO_PREV_VIEW_PROJ, 64);
+    memcpy(fp.camPos, ubo + VKR_UBO_CAM_POS, 12);
+    fp.debugMode = (uint32_t)(ubo[VKR_UBO_IBL_PARAMS + 3] + 0.5f);             // rtao_trace_half.comp:250
+    int rc = (int)(ubo[VKR_UBO_RTAO_PARAMS0 + 1] + 0.5f);                        // :252
+    fp.rayCount = rc < 1 ? 1 : (rc > 16 ? 16 : rc);
+    fp.baseRadius = gmax_h(ubo[VKR_UBO_RTAO_PARAMS0 + 2], 0.01f);                // :253
+    fp.baseBias = gmax_h(ubo[VKR_UBO_RTAO_PARAMS0 + 3], 0.0005f);                // :254
+    fp.frameIndex = ubo[VKR_UBO_RTAO_PARAMS1 + 3];
+    fp.temporalAlphaRaw = ubo[VKR_UBO_RTAO_PARAMS1 + 1];
+    fp.disocclusionRaw = ubo[VKR_UBO_RTAO_PARAMS1 + 2];
+    fp.radiusRaw = ubo[VKR_UBO_RTAO_PARAMS0 + 2];
+    fp.W = (int)c->W;
+    fp.H = (int)c->H;
+    return fp;
+}
+
+int check_io(vkr_ctx* c, const vkr_rtao_frame_io* io, bool need_normal, bool need_out)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!io) return fail(c, VKR_ERR_INVALID_ARG, "io is NULL");
+    if (!io->linear_depth_r16f) return fail(c, VKR_ERR_INVALID_ARG, "linear_depth_r16f is NULL");
+    if (need_normal && !io->normal_rgba16f) return fail(c, VKR_ERR_INVALID_ARG, "normal_rgba16f is NULL");
+    if (need_out && !io->rtao_full_r16f) return fail(c, VKR_ERR_INVALID_ARG, "rtao_full_r16f is NULL");
+    return VKR_OK;
+}
+
+int set_device(vkr_ctx* c) { HIP_OR_FAIL(c, hipSetDevice(c->device)); return VKR_OK; }
+
+}  // namespace
+
+extern "C" {
+
+int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
+{
+    if (!desc || !out) return fail(nullptr, VKR_ERR_INVALID_ARG, "vkr_create: NULL argument");
+    *out = nullptr;
+    if (desc->width == 0 || desc->height == 0 || desc->width > 32768u || desc->height > 32768u)
+        return fail(nullptr, VKR_ERR_INVALID_ARG, "vkr_create: bad extent %ux%u", desc->width, desc->height);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, VKR_ERR_HIP, "vkr_create: no HIP device (%s)", hipGetErrorString(e));
+    if (desc->device < 0 || desc->device >= ndev)
+        return fail(nullptr, VKR_ERR_INVALID_ARG, "vkr_create: device %d out of range (%d devices)", desc->device, ndev);
+    vkr_ctx* c = new vkr_ctx();
+    c->device = desc->device;
+    c->W = desc->width;
+    c->H = desc->height;
+    auto bail = [&](int code, const char* what, hipError_t err) {
+        fail(nullptr, code, "vkr_create: %s: %s", what, hipGetErrorString(err));
+        vkr_destroy(c);
+        return code;
+    };
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return bail(VKR_ERR_HIP, "hipSetDevice", e);
+    size_t px = (size_t)c->W * c->H;
+    for (int i = 0; i < 2; ++i) {
+        if ((e = c->d_hist_img[i].alloc(px)) != hipSuccess) return bail(VKR_ERR_OOM, "history image", e);
+        if ((e = c->d_ping[i].alloc(px)) != hipSuccess) return bail(VKR_ERR_OOM, "ping-pong image", e);
+    }
+    if ((e = c->d_nz.alloc(px)) != hipSuccess) return bail(VKR_ERR_OOM, "A-Trous operand", e);
+    if ((e = c->d_stats.alloc(4)) != hipSuccess) return bail(VKR_ERR_OOM, "counters", e);
+    if ((e = hipMemset(c->d_stats.p, 0, 32)) != hipSuccess) return bail(VKR_ERR_HIP, "hipMemset", e);
+    int rc = vkr_rtao_reset(c, nullptr);
+    if (rc != VKR_OK) { g_create_error = c->err; vkr_destroy(c); return rc; }
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(VKR_ERR_HIP, "hipStreamSynchronize", e);
+    *out = c;
+    return VKR_OK;
+}
+
+void vkr_destroy(vkr_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    c->d_positions.release(); c->d_indices.release(); c->d_uvs.release(); c->d_lut.release();
+    c->d_mesh_class.release(); c->d_material_params.release(); c->d_alpha_tex.release(); c->d_alpha_data.release();
+    c->d_inst_mesh.release(); c->d_inst_first_tri.release(); c->d_inst_xf.release();
+    c->d_nodes.release(); c->d_tris.release(); c->d_perm.release(); c->d_leaf_parent.release();
+    c->d_node_parent.release(); c->d_flags.release();
+    for (int i = 0; i < 2; ++i) { c->d_keys[i].release(); c->d_vals[i].release(); c->d_hist_img[i].release(); c->d_ping[i].release(); }
+    c->d_hist.release(); c->d_digit_totals.release(); c->d_bounds.release(); c->d_height.release();
+    c->d_nz.release(); c->d_stats.release();
+    delete c;
+}
+
+const char* vkr_last_error(const vkr_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int vkr_sync(vkr_ctx* c, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (int rc = set_device(c)) return rc;
+    HIP_OR_FAIL(c, hipStreamSynchronize((hipStream_t)stream));
+    return VKR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ scene
+int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!s) return fail(c, VKR_ERR_INVALID_ARG, "scene is NULL");
+    if ((s->mesh_count && !s->meshes) || (s->instance_count && !s->instances))
+        return fail(c, VKR_ERR_INVALID_ARG, "scene: NULL mesh/instance array");
+    if (int rc = set_device(c)) return rc;
+    c->has_scene = false;
+    c->has_bvh = false;
+
+    // merged buffers exactly as FrameManager::createReflectionBuffers builds them (FrameManager.cpp:1264-1304)
+    std::vector<float> positions;
+    std::vector<uint32_t> indices;
+    std::vector<float2> uvs;
+    std::vector<uint2> lut(s->mesh_count);
+    std::vector<uint32_t> mesh_class(s->mesh_count);
+    c->h_mesh_prims.assign(s->mesh_count, 0);
+    float mp[VKR_MAX_MATERIALS * 4];
+    for (uint32_t m = 0; m < VKR_MAX_MATERIALS; ++m) {  // defaults of FrameManager.cpp:1359-1360
+        mp[4 * m + 0] = s->material_params ? s->material_params[4 * m + 0] : 0.5f;
+        mp[4 * m + 1] = s->material_params ? s->material_params[4 * m + 1] : 0.0f;
+        mp[4 * m + 2] = 0.0f;
+        mp[4 * m + 3] = 0.0f;
+    }
+    uint64_t voff = 0, ioff = 0;
+    for (uint32_t m = 0; m < s->mesh_count; ++m) {
+        const vkr_mesh_desc& md = s->meshes[m];
+        if ((md.vertex_count && !md.positions) || (md.index_count && !md.indices))
+            return fail(c, VKR_ERR_INVALID_ARG, "mesh %u: NULL positions/indices", m);
+        if (md.vertex_count && md.position_stride < 12) return fail(c, VKR_ERR_INVALID_ARG, "mesh %u: position_stride < 12", m);
+        if (md.uvs && md.uv_stride < 8) return fail(c, VKR_ERR_INVALID_ARG, "mesh %u: uv_stride < 8", m);
+        if (voff + md.vertex_count > 0xffffffffull || ioff + md.index_count > 0xffffffffull)
+            return fail(c, VKR_ERR_LIMIT, "scene exceeds 2^32 vertices/indices");
+        int mi = md.material_index;
+        lut[m].x = (mi >= 0 && mi < (int)VKR_MAX_MATERIALS) ? (uint32_t)mi : 0u;  // FrameManager.cpp:1280-1283
+        lut[m].y = (uint32_t)ioff;
+        // AO candidate class: the branch chain of rtao_trace_half.comp:142-173 evaluated per mesh.
+        // opaque geometry never produces a candidate (auto-commit); otherwise alphaMode decides.
+        float mode = mp[4 * lut[m].x + 1];
+        mesh_class[m] = md.opaque ? 0u : (mode < 0.5f ? 0u : (mode > 1.5f ? 1u : 2u));
+        c->h_mesh_prims[m] = md.index_count / 3u;                                 // RayTracingContext.cpp:230
+        for (uint32_t v = 0; v < md.vertex_count; ++v) {
+            const float* p = (const float*)((const char*)md.positions + (size_t)v * md.position_stride);
+            positions.push_back(p[0]); positions.push_back(p[1]); positions.push_back(p[2]);
+            if (md.uvs) {
+                const float* t = (const float*)((const char*)md.uvs + (size_t)v * md.uv_stride);
+                uvs.push_back(make_float2(t[0], t[1]));
+            } else {
+                uvs.push_back(make_float2(0.0f, 0.0f));
+            }
+        }
+        for (uint32_t i = 0; i < md.index_count; ++i) {
+            if (md.indices[i] >= md.vertex_count) return fail(c, VKR_ERR_INVALID_ARG, "mesh %u: index %u out of range", m, i);
+            indices.push_back((uint32_t)voff + md.indices[i]);                   // FrameManager.cpp:1299-1303
+        }
+        voff += md.vertex_count;
+        ioff += md.index_count;
+    }
+    // instances (RayTracingContext::writeInstances, RayTracingContext.cpp:46-71)
+    std::vector<uint32_t> inst_first(s->instance_count + 1, 0);
+    std::vector<float> inst_xf((size_t)s->instance_count * 12);
+    c->h_inst_mesh.resize(s->instance_count);
+    uint64_t tri_total = 0;
+    for (uint32_t i = 0; i < s->instance_count; ++i) {
+        uint32_t m = s->instances[i].mesh_index;
+        if (m >= s->mesh_count) return fail(c, VKR_ERR_INVALID_ARG, "invalid meshIndex for ray tracing instance %u", i);
+        c->h_inst_mesh[i] = m;
+        inst_first[i] = (uint32_t)tri_total;
+        tri_total += c->h_mesh_prims[m];
+        memcpy(&inst_xf[(size_t)i * 12], s->instances[i].transform, 48);
+    }
+    if (tri_total >= (1ull << 28)) return fail(c, VKR_ERR_LIMIT, "scene exceeds 2^28 world-space triangles");
+    if (s->mesh_count >= (1u << 28)) return fail(c, VKR_ERR_LIMIT, "scene exceeds 2^28 meshes");
+    if (s->instance_count) inst_first[s->instance_count] = (uint32_t)tri_total;
+
+    // alpha planes
+    std::vector<AlphaTexDev> tex(VKR_MAX_MATERIALS, AlphaTexDev{0, 0, 0, 0});
+    std::vector<uint8_t> alpha;
+    if (s->alpha_textures) {
+        for (uint32_t m = 0; m < VKR_MAX_MATERIALS; ++m) {
+            const vkr_alpha_texture& t = s->alpha_textures[m];
+            if (!t.alpha || t.width == 0 || t.height == 0) continue;
+            if (t.width > 16384u || t.height > 16384u) return fail(c, VKR_ERR_LIMIT, "alpha texture %u too large", m);
+            tex[m].offset = (uint32_t)alpha.size();
+            tex[m].w = t.width;
+            tex[m].h = t.height;
+            alpha.insert(alpha.end(), t.alpha, t.alpha + (size_t)t.width * t.height);
+            if (alpha.size() > 0xf0000000ull) return fail(c, VKR_ERR_LIMIT, "alpha textures exceed 4 GiB");
+        }
+    }
+
+#define UPLOAD(buf, vec)                                                                                    \
+    do {                                                                                                    \
+        HIP_OR_FAIL(c, (buf).alloc((vec).size() ? (vec).size() : 1));                                       \
+        if ((vec).size())                                                                                   \
+            HIP_OR_FAIL(c, hipMemcpy((buf).p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice)); \
+    } while (0)
+    UPLOAD(c->d_positions, positions);
+    UPLOAD(c->d_indices, indices);
+    UPLOAD(c->d_uvs, uvs);
+    UPLOAD(c->d_lut, lut);
+    UPLOAD(c->d_mesh_class, mesh_class);
+    UPLOAD(c->d_alpha_tex, tex);
+    UPLOAD(c->d_alpha_data, alpha);
+    UPLOAD(c->d_inst_mesh, c->h_inst_mesh);
+    UPLOAD(c->d_inst_first_tri, inst_first);
+    UPLOAD(c->d_inst_xf, inst_xf);
+#undef UPLOAD
+    HIP_OR_FAIL(c, c->d_material_params.alloc(VKR_MAX_MATERIALS));
+    HIP_OR_FAIL(c, hipMemcpy(c->d_material_params.p, mp, sizeof(mp), hipMemcpyHostToDevice));
+
+    c->mesh_count = s->mesh_count;
+    c->instance_count = s->instance_count;
+    c->tri_count = (uint32_t)tri_total;
+    const size_t n = c->tri_count ? c->tri_count : 1;
+    HIP_OR_FAIL(c, c->d_nodes.alloc(n * 4));
+    HIP_OR_FAIL(c, c->d_tris.alloc(n * 3));
+    HIP_OR_FAIL(c, c->d_perm.alloc(n));
+    HIP_OR_FAIL(c, c->d_leaf_parent.alloc(n));
+    HIP_OR_FAIL(c, c->d_node_parent.alloc(n));
+    HIP_OR_FAIL(c, c->d_flags.alloc(n));
+    for (int i = 0; i < 2; ++i) {
+        HIP_OR_FAIL(c, c->d_keys[i].alloc(n));
+        HIP_OR_FAIL(c, c->d_vals[i].alloc(n));
+    }
+    const size_t ntiles = (n + 2047) / 2048;
+    HIP_OR_FAIL(c, c->d_hist.alloc(256 * ntiles));
+    HIP_OR_FAIL(c, c->d_digit_totals.alloc(256));
+    HIP_OR_FAIL(c, c->d_bounds.alloc(1));
+    HIP_OR_FAIL(c, c->d_height.alloc(1));
+    c->has_scene = true;
+    return VKR_OK;
+}
+
+static int finish_build(vkr_ctx* c, hipStream_t st)
+{
+    // height + bounds are tiny; reading them back makes the stack-depth contract checkable here
+    BvhBounds b;
+    uint32_t h = 0;
+    HIP_OR_FAIL(c, hipMemcpyAsync(&h, c->d_height.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_OR_FAIL(c, hipMemcpyAsync(&b, c->d_bounds.p, sizeof(b), hipMemcpyDeviceToHost, st));
+    HIP_OR_FAIL(c, hipStreamSynchronize(st));
+    c->bvh_height = h;
+    for (int k = 0; k < 3; ++k) { c->bounds_min[k] = dec_f(b.tri_min[k]); c->bounds_max[k] = dec_f(b.tri_max[k]); }
+    return VKR_OK;
+}
+
+int vkr_bvh_build(vkr_ctx* c, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!c->has_scene) return fail(c, VKR_ERR_STATE, "vkr_bvh_build before vkr_scene_upload");
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    c->has_bvh = false;
+    c->bvh_height = 0;
+    if (c->tri_count == 0) { c->has_bvh = true; return VKR_OK; }
+    // 21 bits/axis; if the tree comes out deeper than the traversal stack (pathological duplicates), fall back
+    // to 10 bits/axis where the index tie-break bounds the height by 30 + log2(n).
+    const uint32_t tries[2] = {21u, 10u};
+    for (int t = 0; t < 2; ++t) {
+        c->morton_bits = tries[t];
+        HIP_OR_FAIL(c, bvh_build_launch(c, false, st));
+        if (int rc = finish_build(c, st)) return rc;
+        if (c->bvh_height <= (uint32_t)VKR_MAX_STACK) { c->has_bvh = true; return VKR_OK; }
+    }
+    return fail(c, VKR_ERR_LIMIT, "BVH height %u exceeds traversal stack %d", c->bvh_height, VKR_MAX_STACK);
+}
+
+int vkr_bvh_refit(vkr_ctx* c, const vkr_instance* inst, uint32_t count, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_bvh_refit before vkr_bvh_build");
+    if (count != c->instance_count)  // RayTracingContext.cpp:51-53
+        return fail(c, VKR_ERR_INVALID_ARG, "instance count mismatch: RayTracingContext must be re-initialized");
+    if (count && !inst) return fail(c, VKR_ERR_INVALID_ARG, "instances is NULL");
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> xf((size_t)count * 12);
+    for (uint32_t i = 0; i < count; ++i) {
+        if (inst[i].mesh_index != c->h_inst_mesh[i])
+            return fail(c, VKR_ERR_INVALID_ARG, "instance %u: mesh index changed; rebuild required", i);
+        memcpy(&xf[(size_t)i * 12], inst[i].transform, 48);
+    }
+    if (count) {
+        HIP_OR_FAIL(c, hipMemcpyAsync(c->d_inst_xf.p, xf.data(), xf.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_OR_FAIL(c, hipStreamSynchronize(st));  // xf is a stack-lifetime staging vector
+    }
+    if (c->tri_count == 0) return VKR_OK;
+    HIP_OR_FAIL(c, bvh_build_launch(c, true, st));
+    return VKR_OK;
+}
+
+int vkr_bvh_info_get(vkr_ctx* c, vkr_bvh_info* out)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "no BVH");
+    out->triangle_count = c->tri_count;
+    out->node_count = c->tri_count > 1 ? c->tri_count - 1 : (c->tri_count == 1 ? 1 : 0);
+    out->height = c->bvh_height;
+    out->morton_bits = c->morton_bits;
+    for (int k = 0; k < 3; ++k) { out->bounds_min[k] = c->bounds_min[k]; out->bounds_max[k] = c->bounds_max[k]; }
+    return VKR_OK;
+}
+
+int vkr_bvh_download(vkr_ctx* c, float* nodes, float* tris)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "no BVH");
+    if (int rc = set_device(c)) return rc;
+    HIP_OR_FAIL(c, hipDeviceSynchronize());
+    size_t nn = c->tri_count > 1 ? c->tri_count - 1 : (c->tri_count == 1 ? 1 : 0);
+    if (nodes && nn) HIP_OR_FAIL(c, hipMemcpy(nodes, c->d_nodes.p, nn * 64, hipMemcpyDeviceToHost));
+    if (tris && c->tri_count) HIP_OR_FAIL(c, hipMemcpy(tris, c->d_tris.p, (size_t)c->tri_count * 48, hipMemcpyDeviceToHost));
+    return VKR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ RTAO
+int vkr_rtao_reset(vkr_ctx* c, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    size_t px = (size_t)c->W * c->H;
+    for (int i = 0; i < 2; ++i) {  // FrameManager.cpp:1057: cleared to 1.0
+        HIP_OR_FAIL(c, fill_r16f_launch(c->d_hist_img[i].p, px, 1.0f, st));
+        HIP_OR_FAIL(c, fill_r16f_launch(c->d_ping[i].p, px, 1.0f, st));
+    }
+    c->frame_parity = 0;
+    c->last_curr = 0;
+    return VKR_OK;
+}
+
+int vkr_rtao_end_frame(vkr_ctx* c)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    c->last_curr = c->frame_parity;
+    c->frame_parity ^= 1u;  // FrameManager.cpp:1155-1165: curr = currentFrame % MAX_FRAMES_IN_FLIGHT
+    return VKR_OK;
+}
+
+int vkr_rtao_image(vkr_ctx* c, uint32_t which, uint16_t** out)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
+    switch (which) {
+        case 0: *out = c->d_hist_img[c->last_curr].p; break;
+        case 1: *out = c->d_hist_img[c->last_curr ^ 1u].p; break;
+        case 2: *out = c->d_ping[0].p; break;
+        case 3: *out = c->d_ping[1].p; break;
+        default: return fail(c, VKR_ERR_INVALID_ARG, "image selector %u", which);
+    }
+    return VKR_OK;
+}
+
+int vkr_rtao_trace(vkr_ctx* c, const vkr_rtao_frame_io* io, void* stream)
+{
+    if (int rc = check_io(c, io, false, false)) return rc;
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_rtao_trace before vkr_bvh_build");
+    if (int rc = set_device(c)) return rc;
+    FrameParams fp = make_frame_params(c, io->ubo);
+    uint32_t curr = c->frame_parity;
+    HIP_OR_FAIL(c, rtao_trace_launch(c, fp, io->linear_depth_r16f, c->d_hist_img[curr ^ 1u].p, c->d_hist_img[curr].p,
+                                     io->ray_hit_mask, 0, (int)c->H, (hipStream_t)stream));
+    return VKR_OK;
+}
+
+int vkr_rtao_atrous(vkr_ctx* c, const vkr_rtao_frame_io* io, uint32_t step, uint32_t iteration, void* stream)
+{
+    if (int rc = check_io(c, io, true, false)) return rc;
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // rtao_atrous.comp:57-69: dst = iter&1 ; src = iter==0 ? historyCurr : ping[(iter-1)&1]
+    const uint16_t* src = (iteration == 0) ? c->d_hist_img[c->frame_parity].p : c->d_ping[(iteration - 1u) & 1u].p;
+    uint16_t* dst = c->d_ping[iteration & 1u].p;
+    if (iteration == 0) HIP_OR_FAIL(c, rtao_prep_launch(c, io->linear_depth_r16f, io->normal_rgba16f, 0, (int)c->H, st));
+    HIP_OR_FAIL(c, rtao_atrous_launch(c, io->ubo[VKR_UBO_RTAO_PARAMS0 + 2], (int)(step > 0x40000000u ? 0x40000000u : step),
+                                      src, dst, nullptr, 0, (int)c->H, st));
+    return VKR_OK;
+}
+
+int vkr_rtao_upsample(vkr_ctx* c, const vkr_rtao_frame_io* io, uint32_t final_index, void* stream)
+{
+    if (int rc = check_io(c, io, true, true)) return rc;
+    if (int rc = set_device(c)) return rc;
+    uint32_t debugMode = (uint32_t)(io->ubo[VKR_UBO_IBL_PARAMS + 3] + 0.5f);
+    HIP_OR_FAIL(c, rtao_upsample_launch(c, debugMode, c->d_ping[final_index & 1u].p, io->normal_rgba16f,
+                                        io->rtao_full_r16f, 0, (int)c->H, (hipStream_t)stream));
+    return VKR_OK;
+}
+
+int vkr_rtao_execute_band(vkr_ctx* c, const vkr_rtao_frame_io* io, uint32_t y0, uint32_t y1, void* stream)
+{
+    if (int rc = check_io(c, io, true, true)) return rc;
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_rtao_execute before vkr_bvh_build");
+    if (y0 >= y1 || y1 > c->H) return fail(c, VKR_ERR_INVALID_ARG, "band [%u,%u) outside image height %u", y0, y1, c->H);
+    if (io->atrous_iterations > 16u) return fail(c, VKR_ERR_INVALID_ARG, "atrous_iterations %u > 16", io->atrous_iterations);
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = (int)c->H;
+    const uint32_t n = io->atrous_iterations < 1u ? 1u : io->atrous_iterations;  // RtaoComputePass.cpp:529
+    FrameParams fp = make_frame_params(c, io->ubo);
+    const uint32_t curr = c->frame_parity;
+    auto lo = [&](long halo) { long v = (long)y0 - halo; return (int)(v < 0 ? 0 : v); };
+    auto hi = [&](long halo) { long v = (long)y1 + halo; return (int)(v > H ? H : v); };
+    // halo needed below iteration i: taps reach 2*step rows, so rows of the source must extend by
+    // sum_{k>=i} 2*2^k = 2*(2^n - 2^i)
+    const long halo_all = 2L * ((1L << n) - 1L);
+    // dispatchTrace (RtaoComputePass.cpp:503-517)
+    HIP_OR_FAIL(c, rtao_trace_launch(c, fp, io->linear_depth_r16f, c->d_hist_img[curr ^ 1u].p, c->d_hist_img[curr].p,
+                                     io->ray_hit_mask, lo(halo_all), hi(halo_all), st));
+    HIP_OR_FAIL(c, rtao_prep_launch(c, io->linear_depth_r16f, io->normal_rgba16f, lo(halo_all), hi(halo_all), st));
+    // dispatchAtrous (RtaoComputePass.cpp:519-554); the final iteration also writes rtao_full (K3 folded in)
+    const bool fold_upsample = (fp.debugMode != 9u);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint16_t* src = (i == 0) ? c->d_hist_img[curr].p : c->d_ping[(i - 1u) & 1u].p;
+        const long halo_out = 2L * ((1L << n) - (1L << (i + 1)));
+        const bool last = (i + 1 == n);
+        // the rtao_full copy must cover only [y0,y1); with last => halo_out == 0 this holds
+        HIP_OR_FAIL(c, rtao_atrous_launch(c, fp.radiusRaw, 1 << i, src, c->d_ping[i & 1u].p,
+                                          (last && fold_upsample) ? io->rtao_full_r16f : nullptr, lo(halo_out),
+                                          hi(halo_out), st));
+    }
+    // dispatchUpsample (RtaoComputePass.cpp:556-571), only needed as a separate pass for debug view 9
+    if (!fold_upsample)
+        HIP_OR_FAIL(c, rtao_upsample_launch(c, fp.debugMode, c->d_ping[(n - 1u) & 1u].p, io->normal_rgba16f,
+                                            io->rtao_full_r16f, (int)y0, (int)y1, st));
+    vkr_rtao_end_frame(c);
+    return VKR_OK;
+}
+
+int vkr_rtao_execute(vkr_ctx* c, const vkr_rtao_frame_io* io, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    return vkr_rtao_execute_band(c, io, 0, c->H, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ shadows
+int vkr_shadow_sun(vkr_ctx* c, const float* world_pos, const float* geom_normal, const uint8_t* valid,
+                   uint32_t pixel_count, const float L[3], float sun_radius, float sample_count, float* out_vis,
+                   void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!world_pos || !geom_normal || !L || !out_vis) return fail(c, VKR_ERR_INVALID_ARG, "vkr_shadow_sun: NULL argument");
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_shadow_sun before vkr_bvh_build");
+    if (int rc = set_device(c)) return rc;
+    HIP_OR_FAIL(c, shadow_sun_launch(c, world_pos, geom_normal, valid, pixel_count, L, sun_radius, sample_count, out_vis,
+                                     (hipStream_t)stream));
+    return VKR_OK;
+}
+
+int vkr_shadow_point(vkr_ctx* c, const float* world_pos, const float* geom_normal, const uint8_t* valid,
+                     uint32_t pixel_count, const float P[3], float* out_vis, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!world_pos || !geom_normal || !P || !out_vis) return fail(c, VKR_ERR_INVALID_ARG, "vkr_shadow_point: NULL argument");
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_shadow_point before vkr_bvh_build");
+    if (int rc = set_device(c)) return rc;
+    HIP_OR_FAIL(c, shadow_point_launch(c, world_pos, geom_normal, valid, pixel_count, P, out_vis, (hipStream_t)stream));
+    return VKR_OK;
+}
+
+int vkr_gbuffer_primary(vkr_ctx* c, const float ubo[VKR_UBO_FLOATS], uint16_t* depth, uint16_t* normal,
+                        float* world_pos, float* geom_normal, uint8_t* valid, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!ubo) return fail(c, VKR_ERR_INVALID_ARG, "ubo is NULL");
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_gbuffer_primary before vkr_bvh_build");
+    if (int rc = set_device(c)) return rc;
+    FrameParams fp = make_frame_params(c, ubo);
+    HIP_OR_FAIL(c, gbuffer_launch(c, fp, depth, normal, world_pos, geom_normal, valid, (hipStream_t)stream));
+    return VKR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ counters
+int vkr_trace_stats_enable(vkr_ctx* c, int enable)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    c->stats_enabled = enable != 0;
+    return VKR_OK;
+}
+
+int vkr_trace_stats_get(vkr_ctx* c, vkr_trace_stats* out, int reset)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
+    if (int rc = set_device(c)) return rc;
+    HIP_OR_FAIL(c, hipDeviceSynchronize());
+    unsigned long long h[3];
+    HIP_OR_FAIL(c, hipMemcpy(h, c->d_stats.p, 24, hipMemcpyDeviceToHost));
+    out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
+    if (reset) HIP_OR_FAIL(c, hipMemset(c->d_stats.p, 0, 32));
+    return VKR_OK;
+}
+
+}  // extern "C"
