@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the RTAO / shadow-ray path (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of the hot path over resident inputs:
+  workload c3 (default at N=1, BASELINE configs[3]): bistro-class scene, 1920x1080, 8 AO rays/px,
+      trace+temporal + 4 A-Trous iterations (+ upsample folded into the last one), camera dolly 5 cm/frame.
+  workload c4 (default at N>1, BASELINE configs[4]): same scene, 3840x2160, 8 AO rays + 16 sun-disc shadow
+      rays per pixel, row-band sharded over N ranks, one RCCL all-gather per frame (strong scaling).
+G-buffers for all frames are generated on the GPU BEFORE the timed region (inputs resident in HBM).
+value = Mrays/s = rays actually traced (AO + self-hit retries + shadow) / wall time of the K steps, max over ranks.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # name: (W, H, ao_rays, atrous_iters, sun_samples, scene)
+    "c0": (640, 360, 4, 2, 0, "sponza"),
+    "c3": (1920, 1080, 8, 4, 0, "bistro"),
+    "c4": (3840, 2160, 8, 4, 16, "bistro"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c0", "c3", "c4"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip per-kernel timing / counters")
+    return ap.parse_args()
+
+
+def make_scene(kind):
+    from vulkanrenderer_amd import make_bistro_class, make_sponza_class
+    return make_bistro_class() if kind == "bistro" else make_sponza_class()
+
+
+def event_time_ms(fn, stream_sync):
+    """Time one enqueue of `fn` with HIP events on torch's current stream (the stream the kernels are launched on)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def cpu_baseline(scene, wl, ubos, gb0_depth, gb0_normal, target_seconds):
+    """Time the CPU oracle (kind "port") on a bounded sample of the same workload: K1 (trace+temporal) on a band of
+    rows of frame 0, all host threads the box grants us."""
+    from oracle import oracle as O
+    W, H, rays, iters, sun, _ = wl
+    threads = min(16, len(os.sched_getaffinity(0)))
+    O.set_threads(threads)
+    t0 = time.perf_counter()
+    osc = O.OracleScene(scene)
+    build_s = time.perf_counter() - t0
+    hist = np.full((H, W), np.float16(1.0).view(np.uint16), dtype=np.uint16)
+    ymid = H // 2
+    # calibrate on 8 rows, then size the band for ~target_seconds
+    osc.stats(reset=True)
+    t0 = time.perf_counter()
+    osc.trace(ubos[0], gb0_depth, hist, ymid, ymid + 8)
+    dt = time.perf_counter() - t0
+    rows = int(max(8, min(H - ymid, 8 * target_seconds / max(dt, 1e-6))))
+    osc.stats(reset=True)
+    t0 = time.perf_counter()
+    cur = osc.trace(ubos[0], gb0_depth, hist, ymid, ymid + rows)
+    dt = time.perf_counter() - t0
+    st = osc.stats(reset=True)
+    # A-Trous on the same band (one iteration) for the ms/frame side of the metric
+    t1 = time.perf_counter()
+    O.atrous(ubos[0], 1, cur, gb0_depth, gb0_normal, ymid, ymid + rows)
+    dta = time.perf_counter() - t1
+    return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"oracle K1 trace+temporal on rows [{ymid},{ymid + rows}) of frame 0 at {W}x{H}, {rays} rays/px "
+                      f"({st['rays']} rays in {dt:.2f} s; CPU BVH build {build_s:.1f} s not counted); "
+                      f"one A-Trous iteration on the same rows {dta * 1e3:.0f} ms"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = max(1, args.gpus)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert world == n, f"--gpus {n} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from vulkanrenderer_amd import FrameState, camera_path
+    from vulkanrenderer_amd import bands
+    from vulkanrenderer_amd.renderer import (Context, GBuffer, PassExecuteContext, RayTracingContext, RtaoComputePass,
+                                             ShadowRays, generate_gbuffer, trace_stats, trace_stats_enable)
+
+    wl_name = args.workload if args.workload != "auto" else ("c3" if n == 1 else "c4")
+    wl = WORKLOADS[wl_name]
+    W, H, rays, iters, sun_samples, scene_kind = wl
+    K, Wu = args.steps, args.warmup
+    frames = K + Wu
+
+    scene = make_scene(scene_kind)
+    ctx = Context(W, H, local_rank)
+    rt = RayTracingContext(ctx)
+    t0 = time.perf_counter()
+    rt.init(scene)
+    ctx.sync()
+    first_build_s = time.perf_counter() - t0
+    info = rt.info()
+    # LBVH build, timed separately (config names it): rebuild 3x on the resident scene, HIP-event timed
+    build_ms = min(event_time_ms(rt.rebuild, None) for _ in range(3))
+
+    fs = FrameState(W, H, ray_count=rays, sun_samples=max(1, sun_samples))
+    path = camera_path(scene, frames, step=0.05)
+    ubos = [fs.update(e, t) for e, t in path]
+    gbs = []
+    for i in range(frames):
+        gb = GBuffer(ctx, with_shading_inputs=(sun_samples > 0))
+        generate_gbuffer(ctx, ubos[i], gb)
+        gbs.append(gb)
+    ctx.sync()
+
+    rpass = RtaoComputePass(ctx, gbs[0], atrous_iterations=iters)
+    y0, y1 = bands.band_rows(H, n, rank)
+    if n > 1:
+        rpass.band = (y0, y1)
+    shadows = ShadowRays(ctx, gbs[0]) if sun_samples > 0 else None
+    hb = bands.band_height(H, n)
+    packed = torch.zeros((bands.PLANES, hb, W), dtype=torch.int16, device=dev)
+    gathered = torch.zeros((n, bands.PLANES, hb, W), dtype=torch.int16, device=dev)
+    sun16 = torch.zeros((H, W), dtype=torch.float16, device=dev)
+
+    def step(i):
+        rpass.gbuffer = gbs[i]
+        rpass.execute(PassExecuteContext(ubo=ubos[i]))
+        if shadows is not None:
+            shadows.gb = gbs[i]
+            shadows.sun(ubos[i], rows=(y0, y1))
+        if n > 1:
+            # one fused all-gather per frame: [history band | rtao_full band | sun band]
+            sun16[y0:y1].copy_(shadows.sun_vis[y0:y1])
+            hist = rpass.image(0)
+            bands.pack_band([hist, rpass.rtao_full, sun16.view(torch.int16)], H, n, rank, packed)
+            bands.all_gather_frame(packed, gathered)
+            bands.unpack_frame(gathered, [hist, rpass.rtao_full, sun16.view(torch.int16)], H, n)
+
+    for i in range(Wu):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(Wu, Wu + K):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- untimed: count the rays of the timed frames (AO incl. retries via counters; shadow = valid px * samples)
+    trace_stats_enable(ctx, True)
+    trace_stats(ctx, reset=True)
+    rpass.band = None
+    for i in range(Wu, Wu + K):
+        rpass.gbuffer = gbs[i]
+        rpass.dispatchTrace(ubos[i])
+        rpass.endFrame()
+    st = trace_stats(ctx, reset=True)
+    trace_stats_enable(ctx, False)
+    ao_rays = int(st.rays)
+    shadow_rays = 0
+    if sun_samples > 0:
+        shadow_rays = sum(int(gbs[i].valid.sum().item()) for i in range(Wu, Wu + K)) * sun_samples
+    total_rays = ao_rays + shadow_rays
+    value = total_rays / elapsed / 1e6
+
+    out = {
+        "metric": "RTAO Mrays/s (AO + retry + shadow rays traced / wall time of trace+temporal+A-Trous[+sun] frames)",
+        "value": value, "unit": "Mrays/s", "n_gpus": n, "steps": K, "warmup": Wu,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+        "scaling": "strong" if n > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{wl_name}: {scene.name} {W}x{H}, {rays} AO rays/px + temporal + {iters} A-Trous iters"
+                               + (f" + {sun_samples} sun-disc shadow rays/px" if sun_samples else "")
+                               + (f", row-band sharded over {n} GPUs + 1 RCCL all-gather/frame" if n > 1 else ""),
+                   "triangles": info.triangle_count, "instances": int(len(scene.instance_mesh)),
+                   "bvh_height": info.height, "lbvh_build_ms": build_ms,
+                   "rays_per_frame": total_rays / K, "parallelism": f"rowband{n}" if n > 1 else "single"},
+    }
+
+    if rank == 0 and not args.no_extra:
+        # ---- per-kernel timing, HIP events on the launch stream, over the timed frames (single-GPU full frame)
+        rpass.band = None
+        rpass.reset()
+        t_trace, t_atrous, t_up = [], [], []
+        for i in range(Wu, Wu + K):
+            rpass.gbuffer = gbs[i]
+            t_trace.append(event_time_ms(lambda: rpass.dispatchTrace(ubos[i]), None))
+            t_atrous.append(event_time_ms(lambda: rpass.dispatchAtrous(ubos[i]), None))
+            t_up.append(event_time_ms(lambda: rpass.dispatchUpsample(ubos[i]), None))
+            rpass.endFrame()
+        trace_ms = float(np.mean(t_trace))
+        # algorithmic bytes of one K1 launch: 8 B/px of image traffic + BVH traffic
+        # = visited nodes * 64 B + tested triangles * 48 B (this build's node / triangle record sizes)
+        px = W * H
+        bytes_per_launch = 8.0 * px + (st.nodes_visited * 64.0 + st.tris_tested * 48.0) / K
+        achieved = bytes_per_launch / (trace_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_trace (K1 trace+temporal)", "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "launch_ms": trace_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "nodes_per_ray": st.nodes_visited / max(1, ao_rays), "tris_per_ray": st.tris_tested / max(1, ao_rays)}
+        atrous_bytes = 14.0 * px * iters
+        out["kernels"] = {"trace_ms": trace_ms, "atrous_total_ms": float(np.mean(t_atrous)), "upsample_ms": float(np.mean(t_up)),
+                          "ao_mrays_per_s_kernel": ao_rays / K / (trace_ms * 1e-3) / 1e6,
+                          "atrous_gbs_algorithmic": atrous_bytes / (float(np.mean(t_atrous)) * 1e-3) / 1e9,
+                          "first_build_incl_upload_s": first_build_s}
+        if shadows is not None:
+            ts = [event_time_ms(lambda: (setattr(shadows, "gb", gbs[i]), shadows.sun(ubos[i])), None) for i in range(Wu, Wu + min(K, 5))]
+            out["kernels"]["sun_shadow_ms_full_frame"] = float(np.mean(ts))
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                with open(prof) as f:
+                    pj = json.load(f)
+                if pj.get("workload") == wl_name:
+                    out["roofline"]["traffic"] = pj.get("k_trace_hbm_bytes_per_launch")
+            except Exception:
+                pass
+
+    if rank == 0 and n == 1 and args.cpu_seconds > 0:
+        depth0 = gbs[Wu].linear_depth.cpu().numpy().view(np.uint16)
+        normal0 = gbs[Wu].normal.cpu().numpy().view(np.uint16)
+        out["cpu_baseline"] = cpu_baseline(scene, wl, [ubos[Wu]], depth0, normal0, args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""Row-band sharding of the frame over N ranks (no reference counterpart -- the reference is
+single-GPU, Renderer.cpp:359).
+
+Rank r of N owns rows [r*Hb, (r+1)*Hb) with Hb = ceil(H/N) (the last band may be short; buffers are padded to Hb
+so one fixed-size all-gather assembles the frame).  Each rank traces/filters its band plus the A-Trous halo
+(vkr_rtao_execute_band), then ONE all-gather per frame moves a packed R16F buffer
+    [history band | rtao_full band | sun-shadow band]            (6 B/px)
+so every rank holds the full previous history (temporal reprojection is non-local) and the full outputs.
+Device-agnostic torch code: runs over RCCL (backend "nccl") on GPUs and over gloo on CPU in the tests.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+PLANES = 3  # history, rtao_full, sun shadow (all R16F bit patterns in int16)
+
+
+def band_height(H: int, n: int) -> int:
+    return (H + n - 1) // n
+
+
+def band_rows(H: int, n: int, r: int) -> Tuple[int, int]:
+    hb = band_height(H, n)
+    y0 = min(H, r * hb)
+    return y0, min(H, y0 + hb)
+
+
+def atrous_halo(iterations: int) -> int:
+    """Rows of source needed beyond the band for N A-Trous iterations: sum 2*2^i = 2*(2^N - 1)."""
+    n = max(1, int(iterations))
+    return 2 * ((1 << n) - 1)
+
+
+def pack_band(planes: Sequence[torch.Tensor], H: int, n: int, r: int, out: torch.Tensor) -> torch.Tensor:
+    """Copy rows [y0,y1) of each full-frame int16 plane (H, W) into out (PLANES, Hb, W); pad rows stay as they are."""
+    y0, y1 = band_rows(H, n, r)
+    for k, p in enumerate(planes):
+        out[k, : y1 - y0].copy_(p[y0:y1])
+    return out
+
+
+def all_gather_frame(packed: torch.Tensor, gathered: torch.Tensor, group=None) -> torch.Tensor:
+    """packed (PLANES, Hb, W) from every rank -> gathered (n, PLANES, Hb, W).  One collective per frame."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=group)
+    else:
+        gathered.view(-1)[: packed.numel()].copy_(packed.view(-1))
+    return gathered
+
+
+def unpack_frame(gathered: torch.Tensor, planes: Sequence[torch.Tensor], H: int, n: int) -> None:
+    """Scatter gathered (n, PLANES, Hb, W) back into the full-frame planes (each (H, W) int16)."""
+    hb = gathered.shape[2]
+    full_bands = H // hb
+    for k, p in enumerate(planes):
+        if full_bands:
+            p[: full_bands * hb].view(full_bands, hb, -1).copy_(gathered[:full_bands, k])
+        if full_bands < n and full_bands * hb < H:
+            rem = H - full_bands * hb
+            p[full_bands * hb:].copy_(gathered[full_bands, k, :rem])
+
+
+def split_rows(H: int, n: int) -> List[Tuple[int, int]]:
+    return [band_rows(H, n, r) for r in range(n)]
