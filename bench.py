@@ -210,7 +210,7 @@ def main():
                                + (f" + {sun_samples} sun-disc shadow rays/px" if sun_samples else "")
                                + (f", row-band sharded over {n} GPUs + 1 RCCL all-gather/frame" if n > 1 else ""),
                    "triangles": info.triangle_count, "instances": int(len(scene.instance_mesh)),
-                   "bvh_height": info.height, "lbvh_build_ms": build_ms,
+                   "bvh_levels": info.height, "bvh_nodes": info.node_count, "binary_height": info.binary_height, "lbvh_build_ms": build_ms,
                    "rays_per_frame": total_rays / K, "parallelism": f"rowband{n}" if n > 1 else "single"},
     }
 
@@ -234,7 +234,9 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "k_trace (K1 trace+temporal)", "achieved": achieved,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                            "launch_ms": trace_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "nodes_per_ray": st.nodes_visited / max(1, ao_rays), "tris_per_ray": st.tris_tested / max(1, ao_rays)}
+                           "nodes_per_ray": st.nodes_visited / max(1, ao_rays), "tris_per_ray": st.tris_tested / max(1, ao_rays),
+                           "lane_util_node_loop": st.nodes_visited / max(1, 64 * st.wave_node_iters),
+                           "lane_util_tri_loop": st.tris_tested / max(1, 64 * st.wave_tri_iters)}
         atrous_bytes = 14.0 * px * iters
         out["kernels"] = {"trace_ms": trace_ms, "atrous_total_ms": float(np.mean(t_atrous)), "upsample_ms": float(np.mean(t_up)),
                           "ao_mrays_per_s_kernel": ao_rays / K / (trace_ms * 1e-3) / 1e6,

@@ -149,10 +149,11 @@ VKR_API int vkr_bvh_build(vkr_ctx* ctx, void* stream);
 VKR_API int vkr_bvh_refit(vkr_ctx* ctx, const vkr_instance* instances, uint32_t count, void* stream);
 
 typedef struct vkr_bvh_info {
-    uint32_t triangle_count; /* flattened world-space triangles = leaves            */
-    uint32_t node_count;     /* internal nodes (triangle_count - 1, or 0)           */
-    uint32_t height;         /* longest root->leaf path, in internal nodes          */
-    uint32_t morton_bits;    /* bits per axis used by the last build (21 or 10)     */
+    uint32_t triangle_count; /* flattened world-space triangles                      */
+    uint32_t node_count;     /* wide (4-ary) nodes                                   */
+    uint32_t height;         /* levels of wide nodes, root = 1                       */
+    uint32_t morton_bits;    /* bits per axis used by the last build (21 or 10)      */
+    uint32_t binary_height;  /* height of the intermediate binary LBVH               */
     float bounds_min[3];
     float bounds_max[3];
 } vkr_bvh_info;
@@ -160,9 +161,11 @@ typedef struct vkr_bvh_info {
 VKR_API int vkr_bvh_info_get(vkr_ctx* ctx, vkr_bvh_info* out);
 
 /* Debug/inspection copies of the BVH to HOST memory for structural tests (no reference counterpart:
- * the Vulkan AS is opaque).  nodes: node_count x 16 floats
- * {lmin xyz, lmax xyz, rmin xyz, rmax xyz, left(bits), right(bits), 0, 0}; child < 0 => leaf ~child.
- * tris: triangle_count x 12 floats {v0 xyz, mesh(bits), e1 xyz, prim(bits), e2 xyz, flags(bits)}. */
+ * the Vulkan AS is opaque).  nodes: node_count x 32 floats
+ * {minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4], child[4](bits), build refs[4](bits)};
+ * child >= 0: wide node; child < 0: leaf, x = ~child, first = x & 0x0fffffff, count = ((x>>28)&7)+1;
+ * 0x7fffffff: unused slot.  Root = node 0.
+ * tris: triangle_count x 12 floats {v0 xyz, mesh|class<<28 (bits), e1 xyz, prim(bits), e2 xyz, flat id(bits)}. */
 VKR_API int vkr_bvh_download(vkr_ctx* ctx, float* nodes, float* tris);
 
 /* ---------------------------------------------------------------- RTAO pass ------------- */
@@ -239,6 +242,8 @@ typedef struct vkr_trace_stats {
     uint64_t rays;          /* ray queries issued (AO rays + retries)      */
     uint64_t nodes_visited; /* internal nodes popped                        */
     uint64_t tris_tested;   /* ray/triangle tests                           */
+    uint64_t wave_node_iters; /* node-loop iterations counted once per wave (lane utilisation = nodes_visited / (64*this)) */
+    uint64_t wave_tri_iters;  /* triangle-loop iterations counted once per wave */
 } vkr_trace_stats;
 /* Enable (1) / disable (0) traversal counters for subsequent AO traces (slower kernel variant), and read
  * them back (synchronises).  Feeds bench.py's algorithmic-bytes figure. */

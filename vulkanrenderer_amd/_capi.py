@@ -40,7 +40,7 @@ class SceneDesc(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("triangle_count", C.c_uint32), ("node_count", C.c_uint32), ("height", C.c_uint32),
-                ("morton_bits", C.c_uint32), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3)]
+                ("morton_bits", C.c_uint32), ("binary_height", C.c_uint32), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3)]
 
 
 class RtaoFrameIO(C.Structure):
@@ -50,7 +50,8 @@ class RtaoFrameIO(C.Structure):
 
 
 class TraceStats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_node_iters", C.c_uint64),
+                ("wave_tri_iters", C.c_uint64)]
 
 
 # every symbol include/vkr_rt.h declares: name -> (restype, argtypes)

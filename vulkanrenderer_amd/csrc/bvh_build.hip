@@ -305,8 +305,9 @@ VKR_DI int delta(const uint64_t* keys, int n, int i, int j)
     return __clzll((long long)(a ^ b));
 }
 
-__global__ __launch_bounds__(256) void k_hierarchy(const uint64_t* keys, int n, float* nodes, uint32_t* leaf_parent,
-                                                   uint32_t* node_parent)
+// binary child encoding: >= 0 internal node, < 0 leaf ~index.  bin_range = [first, last] sorted-triangle range.
+__global__ __launch_bounds__(256) void k_hierarchy(const uint64_t* keys, int n, int2* bin_child, uint2* bin_range,
+                                                   uint32_t* leaf_parent, uint32_t* node_parent)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n - 1) return;
@@ -331,83 +332,236 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint64_t* keys, int n, 
     else { left = gamma; node_parent[gamma] = (uint32_t)i; }
     if (hi == gamma + 1) { right = ~(gamma + 1); leaf_parent[gamma + 1] = (uint32_t)i; }
     else { right = gamma + 1; node_parent[gamma + 1] = (uint32_t)i; }
-    float* nd = nodes + (size_t)i * 16;
-    nd[12] = u2f((uint32_t)left);
-    nd[13] = u2f((uint32_t)right);
+    bin_child[i] = make_int2(left, right);
+    bin_range[i] = make_uint2((uint32_t)lo, (uint32_t)hi);
     if (i == 0) node_parent[0] = 0xffffffffu;
 }
 
-// ---------------------------------------------------------------- bottom-up fit --------------------------
-// One thread per leaf walks towards the root; at each node the first arrival stores its child box and stops,
-// the second arrival (which sees the sibling's box after an agent-scope fence) continues with the union.
-// flags[] must be zero on entry.
-__global__ __launch_bounds__(256) void k_fit(const float4* tris, int n, float* nodes, const uint32_t* leaf_parent,
-                                             const uint32_t* node_parent, uint32_t* flags, uint32_t* height_out)
+// padded AABB of sorted triangle j (padding keeps the slab test conservative w.r.t. the triangle test)
+VKR_DI void tri_box(const float4* tris, uint32_t j, float lo[3], float hi[3])
 {
-    int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
     const float4* tp = tris + (size_t)j * 3;
     float4 a = tp[0], b = tp[1], c = tp[2];
-    float lo[3], hi[3];
-    {
-        float v0[3] = {a.x, a.y, a.z};
-        float v1[3] = {a.x + b.x, a.y + b.y, a.z + b.z};
-        float v2[3] = {a.x + c.x, a.y + c.y, a.z + c.z};
+    float v0[3] = {a.x, a.y, a.z};
+    float v1[3] = {a.x + b.x, a.y + b.y, a.z + b.z};
+    float v2[3] = {a.x + c.x, a.y + c.y, a.z + c.z};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float l = __builtin_fminf(v0[k], __builtin_fminf(v1[k], v2[k]));
-            float h = __builtin_fmaxf(v0[k], __builtin_fmaxf(v1[k], v2[k]));
-            float pad = 1e-5f * __builtin_fmaxf(__builtin_fabsf(l), __builtin_fabsf(h)) + 1e-6f;
-            lo[k] = l - pad;
-            hi[k] = h + pad;
-        }
-    }
-    uint32_t child = (uint32_t)(~j);
-    uint32_t p = leaf_parent[j];
-    uint32_t h = 0;  // height of the subtree rooted at `child`, in internal nodes
-    while (true) {
-        float* nd = nodes + (size_t)p * 16;
-        bool is_left = (f2u(nd[12]) == child);
-        float* slot = nd + (is_left ? 0 : 6);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { slot[k] = lo[k]; slot[3 + k] = hi[k]; }
-        nd[is_left ? 14 : 15] = u2f(h);
-        __threadfence();
-        uint32_t old = atomicAdd(&flags[p], 1u);
-        if (old == 0u) return;
-        __threadfence();
-        const volatile float* sib = nd + (is_left ? 6 : 0);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = __builtin_fminf(lo[k], sib[k]);
-            hi[k] = __builtin_fmaxf(hi[k], sib[3 + k]);
-        }
-        uint32_t hs = f2u(((const volatile float*)nd)[is_left ? 15 : 14]);
-        h = (h > hs ? h : hs) + 1u;
-        if (p == 0u) { *height_out = h; return; }
-        child = p;
-        p = node_parent[p];
-    }
-}
-
-// n == 1: a root whose two children are the same leaf
-__global__ void k_single(const float4* tris, float* nodes, uint32_t* height_out)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float4 a = tris[0], b = tris[1], c = tris[2];
-    float v0[3] = {a.x, a.y, a.z}, v1[3] = {a.x + b.x, a.y + b.y, a.z + b.z}, v2[3] = {a.x + c.x, a.y + c.y, a.z + c.z};
     for (int k = 0; k < 3; ++k) {
         float l = __builtin_fminf(v0[k], __builtin_fminf(v1[k], v2[k]));
         float h = __builtin_fmaxf(v0[k], __builtin_fmaxf(v1[k], v2[k]));
         float pad = 1e-5f * __builtin_fmaxf(__builtin_fabsf(l), __builtin_fabsf(h)) + 1e-6f;
-        nodes[k] = l - pad; nodes[3 + k] = h + pad; nodes[6 + k] = l - pad; nodes[9 + k] = h + pad;
+        lo[k] = l - pad;
+        hi[k] = h + pad;
     }
-    nodes[12] = u2f(~0u); nodes[13] = u2f(~0u); nodes[14] = 0.0f; nodes[15] = 0.0f;
+}
+
+// ---------------------------------------------------------------- bottom-up fit (binary tree) ------------
+// One thread per leaf walks towards the root.  At each node the first arrival deposits its box in the node's
+// left/right hand-off slot and stops; the second arrival reads the sibling's deposit and continues with the
+// union, which it also records as node_box[p] for the wide-node pass.
+// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16, R1 + "value its add returned" form): every
+// deposited byte is stored write-through at agent scope (8-byte relaxed agent atomic stores = sc1), the storing
+// wave drains them (s_waitcnt vmcnt(0)) before its returning atomic add on the arrival counter, and the consumer's
+// loads of the deposit are agent-scope (sc1) loads issued after its own add returned 1.  No L2 write-back fence.
+// flags[] must be zero on entry.
+typedef unsigned long long u64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+VKR_DI u64 pack2(float a, float b) { return (u64)f2u(a) | ((u64)f2u(b) << 32); }
+
+__global__ __launch_bounds__(256) void k_fit(const float4* tris, int n, const int2* bin_child, u64* deposit,
+                                             float4* node_box, const uint32_t* leaf_parent,
+                                             const uint32_t* node_parent, uint32_t* flags, uint32_t* height_out)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float lo[3], hi[3];
+    tri_box(tris, (uint32_t)j, lo, hi);
+    int child = ~j;
+    uint32_t p = leaf_parent[j];
+    uint32_t h = 0;  // height of the subtree rooted at `child`, in internal nodes
+    while (true) {
+        const bool is_left = (bin_child[p].x == child);
+        u64* mine = deposit + (size_t)p * 8 + (is_left ? 0 : 4);
+        u64* sib = deposit + (size_t)p * 8 + (is_left ? 4 : 0);
+        __hip_atomic_store(mine + 0, pack2(lo[0], lo[1]), RLX_AGENT);
+        __hip_atomic_store(mine + 1, pack2(lo[2], u2f(h)), RLX_AGENT);
+        __hip_atomic_store(mine + 2, pack2(hi[0], hi[1]), RLX_AGENT);
+        __hip_atomic_store(mine + 3, pack2(hi[2], 0.0f), RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t old = __hip_atomic_fetch_add(&flags[p], 1u, RLX_AGENT);
+        if (old == 0u) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: keep the loads below the add
+        u64 s0 = __hip_atomic_load(sib + 0, RLX_AGENT), s1 = __hip_atomic_load(sib + 1, RLX_AGENT);
+        u64 s2 = __hip_atomic_load(sib + 2, RLX_AGENT), s3 = __hip_atomic_load(sib + 3, RLX_AGENT);
+        lo[0] = __builtin_fminf(lo[0], u2f((uint32_t)s0)); lo[1] = __builtin_fminf(lo[1], u2f((uint32_t)(s0 >> 32)));
+        lo[2] = __builtin_fminf(lo[2], u2f((uint32_t)s1));
+        hi[0] = __builtin_fmaxf(hi[0], u2f((uint32_t)s2)); hi[1] = __builtin_fmaxf(hi[1], u2f((uint32_t)(s2 >> 32)));
+        hi[2] = __builtin_fmaxf(hi[2], u2f((uint32_t)s3));
+        uint32_t hs = (uint32_t)(s1 >> 32);
+        h = (h > hs ? h : hs) + 1u;
+        node_box[(size_t)p * 2 + 0] = make_float4(lo[0], lo[1], lo[2], u2f(h));
+        node_box[(size_t)p * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        if (p == 0u) { *height_out = h; return; }
+        child = (int)p;
+        p = node_parent[p];
+    }
+}
+
+// ---------------------------------------------------------------- wide (4-ary) nodes ---------------------
+// Collapse of the binary LBVH, breadth-first: wide node w stands for binary node wide_bin[w]; its children are
+// found by opening, up to twice, the largest-area child that is still worth a node of its own (more than
+// VKR_LEAF_MAX triangles).  Subtrees with <= VKR_LEAF_MAX triangles become one leaf (their triangles are
+// contiguous in Morton order).  Wide nodes are numbered in BFS order, so each level is the work list of the
+// next launch and the top of the tree is contiguous in memory.
+struct WideCtl {
+    uint32_t count;          // wide nodes allocated so far
+    uint32_t level_begin;    // current level = [level_begin, level_end)
+    uint32_t level_end;
+    uint32_t levels;         // non-empty levels processed
+};
+
+VKR_DI float half_area(const float4& mn, const float4& mx)
+{
+    float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+VKR_DI void cand_box(int c, const float4* node_box, const float4* tris, float lo[3], float hi[3])
+{
+    if (c >= 0) {
+        float4 mn = node_box[(size_t)c * 2], mx = node_box[(size_t)c * 2 + 1];
+        lo[0] = mn.x; lo[1] = mn.y; lo[2] = mn.z; hi[0] = mx.x; hi[1] = mx.y; hi[2] = mx.z;
+    } else {
+        tri_box(tris, (uint32_t)(~c), lo, hi);
+    }
+}
+
+// writes boxes (q0..q5) of wide node w from its children's binary refs (q7)
+VKR_DI void write_wide_boxes(float4* node, const int cand[4], int ncand, const float4* node_box, const float4* tris)
+{
+    float mn[3][4], mx[3][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {3.0e38f, 3.0e38f, 3.0e38f};
+        if (k < ncand) cand_box(cand[k], node_box, tris, lo, hi);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a][k] = lo[a]; mx[a][k] = hi[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        node[a] = make_float4(mn[a][0], mn[a][1], mn[a][2], mn[a][3]);
+        node[3 + a] = make_float4(mx[a][0], mx[a][1], mx[a][2], mx[a][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bin_child, const uint2* bin_range,
+                                                    const float4* node_box, const float4* tris, float4* nodes,
+                                                    uint32_t* wide_bin)
+{
+    const uint32_t begin = ctl->level_begin, end = ctl->level_end;
+    uint32_t w = begin + blockIdx.x * 256u + threadIdx.x;
+    if (w >= end) return;
+    int b = (int)wide_bin[w];
+    int cand[4];
+    int ncand = 2;
+    { int2 c = bin_child[b]; cand[0] = c.x; cand[1] = c.y; cand[2] = 0; cand[3] = 0; }
+    auto tri_count = [&](int c) -> uint32_t {
+        if (c < 0) return 1u;
+        uint2 r = bin_range[c];
+        return r.y - r.x + 1u;
+    };
+    for (int round = 0; round < 2; ++round) {
+        int pick = -1;
+        float best = -1.0f;
+        for (int k = 0; k < ncand; ++k) {
+            int c = cand[k];
+            if (c < 0 || tri_count(c) <= (uint32_t)VKR_LEAF_MAX) continue;
+#ifdef VKR_COLLAPSE_BY_COUNT
+            float a = (float)tri_count(c);
+#else
+            float a = half_area(node_box[(size_t)c * 2], node_box[(size_t)c * 2 + 1]);
+#endif
+            if (a > best) { best = a; pick = k; }
+        }
+        if (pick < 0) break;
+        int2 c = bin_child[cand[pick]];
+        cand[pick] = c.x;
+        cand[ncand++] = c.y;
+    }
+    float4* node = nodes + (size_t)w * 8;
+    write_wide_boxes(node, cand, ncand, node_box, tris);
+    uint32_t ref[4], bref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ref[k] = VKR_CHILD_NONE;
+        bref[k] = VKR_CHILD_NONE;
+        if (k < ncand) {
+            int c = cand[k];
+            bref[k] = (uint32_t)c;
+            uint32_t cnt = tri_count(c);
+            if (c >= 0 && cnt > (uint32_t)VKR_LEAF_MAX) {
+                uint32_t idx = atomicAdd(&ctl->count, 1u);
+                wide_bin[idx] = (uint32_t)c;
+                ref[k] = idx;
+            } else {
+                uint32_t first = (c >= 0) ? bin_range[c].x : (uint32_t)(~c);
+                ref[k] = ~(first | ((cnt - 1u) << 28));
+            }
+        }
+    }
+    node[6] = make_float4(u2f(ref[0]), u2f(ref[1]), u2f(ref[2]), u2f(ref[3]));
+    node[7] = make_float4(u2f(bref[0]), u2f(bref[1]), u2f(bref[2]), u2f(bref[3]));
+}
+
+__global__ void k_wide_init(WideCtl* ctl, uint32_t* wide_bin)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl->count = 1; ctl->level_begin = 0; ctl->level_end = 1; ctl->levels = 0;
+        wide_bin[0] = 0;
+    }
+}
+
+__global__ void k_wide_next(WideCtl* ctl)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (ctl->level_end > ctl->level_begin) ctl->levels += 1;
+        ctl->level_begin = ctl->level_end;
+        ctl->level_end = ctl->count;
+    }
+}
+
+// refit: same topology, new boxes
+__global__ __launch_bounds__(256) void k_wide_refit(uint32_t count, const float4* node_box, const float4* tris,
+                                                    float4* nodes)
+{
+    uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= count) return;
+    float4* node = nodes + (size_t)w * 8;
+    float4 br = node[7];
+    int cand[4] = {(int)f2u(br.x), (int)f2u(br.y), (int)f2u(br.z), (int)f2u(br.w)};
+    int ncand = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (f2u(k == 0 ? br.x : k == 1 ? br.y : k == 2 ? br.z : br.w) != VKR_CHILD_NONE) ncand = k + 1;
+    write_wide_boxes(node, cand, ncand, node_box, tris);
+}
+
+// n == 1: a root with one single-triangle leaf
+__global__ void k_single(const float4* tris, float4* nodes, uint32_t* height_out, WideCtl* ctl)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int cand[4] = {~0, 0, 0, 0};
+    write_wide_boxes(nodes, cand, 1, nullptr, tris);
+    nodes[6] = make_float4(u2f(~0u), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE));
+    nodes[7] = nodes[6];
     *height_out = 1u;
+    ctl->count = 1; ctl->levels = 1; ctl->level_begin = 1; ctl->level_end = 1;
 }
 
 #define VKR_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
+// Stage 1 of a build (everything up to the binary fit); the host reads back the binary height, then stage 2
+// collapses to wide nodes.  refit_only: stage 1 re-transforms + refits, stage 2 regathers wide boxes.
 hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
 {
     const uint32_t n = c->tri_count;
@@ -417,7 +571,6 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     in.mesh_class = c->d_mesh_class.p; in.inst_mesh = c->d_inst_mesh.p; in.inst_first_tri = c->d_inst_first_tri.p;
     in.inst_xf = c->d_inst_xf.p; in.instance_count = c->instance_count; in.tri_count = n;
     const uint32_t nb = (n + 255u) / 256u;
-    float* nodes = (float*)c->d_nodes.p;
 
     if (!refit_only) {
         k_bounds_init<<<1, 64, 0, st>>>(c->d_bounds.p);
@@ -435,20 +588,40 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
             cur ^= 1;
         }
         VKR_TRY(hipMemcpyAsync(c->d_perm.p, c->d_vals[cur].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-        if (cur != 0)
-            VKR_TRY(hipMemcpyAsync(c->d_keys[0].p, c->d_keys[1].p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-        if (n > 1) {
-            k_hierarchy<<<(n - 1 + 255u) / 256u, 256, 0, st>>>(c->d_keys[0].p, (int)n, nodes, c->d_leaf_parent.p,
-                                                             c->d_node_parent.p);
-        }
+        if (n > 1)
+            k_hierarchy<<<(n - 1 + 255u) / 256u, 256, 0, st>>>(c->d_keys[cur].p, (int)n, c->d_bin_child.p,
+                                                             c->d_bin_range.p, c->d_leaf_parent.p, c->d_node_parent.p);
     }
     k_emit_sorted<<<nb, 256, 0, st>>>(in, c->d_perm.p, c->d_tris.p);
     if (n == 1) {
-        k_single<<<1, 64, 0, st>>>(c->d_tris.p, nodes, c->d_height.p);
-    } else {
-        VKR_TRY(hipMemsetAsync(c->d_flags.p, 0, (size_t)(n - 1) * 4, st));
-        k_fit<<<nb, 256, 0, st>>>(c->d_tris.p, (int)n, nodes, c->d_leaf_parent.p, c->d_node_parent.p, c->d_flags.p,
-                                  c->d_height.p);
+        k_single<<<1, 64, 0, st>>>(c->d_tris.p, c->d_nodes.p, c->d_height.p, (WideCtl*)c->d_wide_ctl.p);
+        return hipGetLastError();
+    }
+    VKR_TRY(hipMemsetAsync(c->d_flags.p, 0, (size_t)(n - 1) * 4, st));
+    k_fit<<<nb, 256, 0, st>>>(c->d_tris.p, (int)n, c->d_bin_child.p, (u64*)c->d_deposit.p, c->d_node_box.p,
+                              c->d_leaf_parent.p, c->d_node_parent.p, c->d_flags.p, c->d_height.p);
+    if (refit_only) {
+        k_wide_refit<<<(c->wide_count + 255u) / 256u, 256, 0, st>>>(c->wide_count, c->d_node_box.p, c->d_tris.p,
+                                                                    c->d_nodes.p);
+    }
+    return hipGetLastError();
+}
+
+// Stage 2: BFS collapse; `bin_height` bounds the number of levels.
+hipError_t bvh_wide_launch(vkr_ctx* c, uint32_t bin_height, hipStream_t st)
+{
+    const uint32_t n = c->tri_count;
+    if (n <= 1) return hipSuccess;
+    WideCtl* ctl = (WideCtl*)c->d_wide_ctl.p;
+    k_wide_init<<<1, 64, 0, st>>>(ctl, c->d_wide_bin.p);
+    uint64_t cap = 1;
+    for (uint32_t level = 0; level < bin_height + 1; ++level) {
+        uint64_t width = cap < (uint64_t)n ? cap : (uint64_t)n;   // a level never holds more than 4^level nodes
+        k_wide_level<<<(uint32_t)((width + 255u) / 256u), 256, 0, st>>>(ctl, c->d_bin_child.p, c->d_bin_range.p,
+                                                                        c->d_node_box.p, c->d_tris.p, c->d_nodes.p,
+                                                                        c->d_wide_bin.p);
+        k_wide_next<<<1, 64, 0, st>>>(ctl);
+        if (cap < (uint64_t)n) cap *= 4;
     }
     return hipGetLastError();
 }

@@ -89,7 +89,13 @@ struct vkr_ctx {
     bool has_bvh = false;
     uint32_t morton_bits = 21;
     uint32_t bvh_height = 0;
-    vkr::DevBuf<float4> d_nodes;             // 4 x float4 per internal node
+    uint32_t wide_count = 0, wide_levels = 0;
+    vkr::DevBuf<float4> d_nodes;             // 8 x float4 per wide node (traverse.hpp)
+    vkr::DevBuf<int2> d_bin_child;           // binary LBVH (build/refit only)
+    vkr::DevBuf<uint2> d_bin_range;
+    vkr::DevBuf<unsigned long long> d_deposit;  // 8 x u64 per binary node: fit hand-off slots
+    vkr::DevBuf<float4> d_node_box;          // 2 x float4 per binary node: min.xyz|height, max.xyz
+    vkr::DevBuf<uint32_t> d_wide_ctl, d_wide_bin;
     vkr::DevBuf<float4> d_tris;              // 3 x float4 per leaf, Morton order
     vkr::DevBuf<uint32_t> d_perm;            // sorted position -> flat triangle id
     vkr::DevBuf<uint32_t> d_leaf_parent, d_node_parent, d_flags;
@@ -103,6 +109,7 @@ struct vkr_ctx {
 
     // ---- RTAO images (FrameManager::createRtaoComputeTextures)
     vkr::DevBuf<uint16_t> d_hist_img[2], d_ping[2];
+    vkr::DevBuf<float4> d_raybuf;            // K1 ray slices: per wave (2 float4/ray + results), grow-only
     vkr::DevBuf<float4> d_nz;                // per-frame decoded normal.xyz + clamped depth (A-Trous operand)
     uint32_t frame_parity = 0;               // FrameManager currentFrame % 2
     uint32_t last_curr = 0;
@@ -131,6 +138,7 @@ inline SceneDev scene_dev(const vkr_ctx* c)
 
 // bvh_build.hip
 hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st);
+hipError_t bvh_wide_launch(vkr_ctx* c, uint32_t bin_height, hipStream_t st);
 // rtao_kernels.hip
 hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,
                              uint16_t* hist_curr, uint32_t* hit_mask, int y0, int y1, hipStream_t st);

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_shadow_sun(SceneDev sc, con
                                                                 float sunAngularRadius, float sampleCountF,
                                                                 float* out)
 {
-    __shared__ uint32_t s_stack[VKR_LDS_STACK * VKR_TRACE_BLOCK];
+    __shared__ uint32_t s_stack[2 * VKR_LDS_STACK * VKR_TRACE_BLOCK];
     uint32_t* stack = s_stack + threadIdx.x;
     uint32_t i = blockIdx.x * VKR_TRACE_BLOCK + threadIdx.x;
     if (i >= count) return;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_shadow_point(SceneDev sc, c
                                                                   const uint8_t* valid, uint32_t count, V3 lightPos,
                                                                   float* out)
 {
-    __shared__ uint32_t s_stack[VKR_LDS_STACK * VKR_TRACE_BLOCK];
+    __shared__ uint32_t s_stack[2 * VKR_LDS_STACK * VKR_TRACE_BLOCK];
     uint32_t* stack = s_stack + threadIdx.x;
     uint32_t i = blockIdx.x * VKR_TRACE_BLOCK + threadIdx.x;
     if (i >= count) return;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer(SceneDev sc, FrameP
                                                              uint16_t* normal, float* wpOut, float* ngOut,
                                                              uint8_t* validOut, uint32_t tiles_x)
 {
-    __shared__ uint32_t s_stack[VKR_LDS_STACK * VKR_TRACE_BLOCK];
+    __shared__ uint32_t s_stack[2 * VKR_LDS_STACK * VKR_TRACE_BLOCK];
     uint32_t* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = (int)(blockIdx.x % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);

@@ -1,20 +1,32 @@
-// traverse.hpp -- ray queries over the LBVH (replaces rayQueryEXT + the driver's TLAS/BLAS walk).
+// traverse.hpp -- ray queries over the wide LBVH (replaces rayQueryEXT + the driver's TLAS/BLAS walk).
 //
-// Data layout in HBM (all 16-byte aligned, one dwordx4 load per quarter):
-//   node (64 B)  : q0 = lmin.xyz lmax.x | q1 = lmax.yz rmin.xy | q2 = rmin.z rmax.xyz | q3 = left right hL hR
-//                  child >= 0 : internal node index ; child < 0 : leaf, triangle index = ~child
-//   tri  (48 B)  : q0 = v0.xyz  (mesh | class<<28) | q1 = e1.xyz prim | q2 = e2.xyz flat_id
-//                  class: 0 = always an occluder for AO, 1 = never (BLEND), 2 = alpha-test (MASK)
-// Traversal: one ray per lane, near-child-first, short stack in LDS ([depth][lane], conflict-free) that
-// spills to per-lane scratch only beyond VKR_LDS_STACK entries.
+// Data layout in HBM (16-byte aligned, read as dwordx4 quarters):
+//   wide node (128 B = one cache line, up to 4 children, SoA so one quarter feeds four slab tests):
+//       q0 minx[4] | q1 miny[4] | q2 minz[4] | q3 maxx[4] | q4 maxy[4] | q5 maxz[4] | q6 child[4] | q7 build refs
+//       child >= 0            : wide node index
+//       child <  0            : leaf, x = ~child: first triangle = x & 0x0fffffff, count = ((x >> 28) & 7) + 1
+//       unused slot           : box min = max = 3e38 (never hit), child = 0x7fffffff
+//   tri (48 B, Morton order so a leaf's triangles are contiguous):
+//       q0 = v0.xyz (mesh | class<<28) | q1 = e1.xyz prim | q2 = e2.xyz flat_id
+//       class: 0 = always an occluder for AO, 1 = never (BLEND), 2 = alpha-test (MASK)
+// Traversal: one ray per lane, "while-while": lanes walk internal nodes until each holds a leaf, then the wave
+// tests leaves together.  Hit children are ordered near-to-far with a 5-exchange network on packed
+// (tnear bits | slot) keys; the deferred ones go to a short stack in LDS ([depth][lane], conflict-free) that
+// spills to per-lane scratch only beyond VKR_LDS_STACK entries.  Entries carry tnear so stale ones are culled
+// at pop time against the current closest hit.
 #pragma once
 #include "device_math.hpp"
 
 namespace vkr {
 
-constexpr int VKR_LDS_STACK = 16;   // entries per lane kept in LDS
-constexpr int VKR_MAX_STACK = 96;   // hard cap (host checks BVH height against it)
+constexpr int VKR_LDS_STACK = 12;    // entries per lane kept in LDS (2 dwords each)
+constexpr int VKR_MAX_STACK = 96;    // hard cap; the host checks 3*levels+1 against it after every build
 constexpr int VKR_TRACE_BLOCK = 256;
+constexpr int VKR_LEAF_MAX = 4;      // triangles per leaf (encoding allows 8)
+constexpr uint32_t VKR_CHILD_NONE = 0x7fffffffu;
+#ifndef VKR_LEAF_VOTE
+#define VKR_LEAF_VOTE 4   // K1 runs a triangle step when n_leaf * VKR_LEAF_VOTE >= n_node
+#endif
 
 struct AlphaTexDev { uint32_t offset, w, h, pad; };
 
@@ -35,7 +47,7 @@ struct HitDev { float t; uint32_t tri; float u, v; };
 
 enum { Q_AO = 0, Q_SHADOW = 1, Q_PRIMARY = 2 };
 
-struct TraceCounters { uint32_t nodes, tris; };
+struct TraceCounters { uint32_t nodes, tris, wave_node_iters, wave_tri_iters; };
 
 // baseColor alpha: LOD 0, bilinear, REPEAT (rtao_trace_half.comp:170)
 VKR_DI float sample_alpha(const SceneDev& sc, uint32_t mat, V2 uv)
@@ -75,9 +87,10 @@ VKR_DI bool alpha_test(const SceneDev& sc, uint32_t mesh, uint32_t prim, float b
     return sample_alpha(sc, lut.x, uv) >= cutoff;
 }
 
-// Slab test of one child box against [tmin, tbest]; padded so rounding can only add visits.
-VKR_DI bool box_hit(float minx, float miny, float minz, float maxx, float maxy, float maxz, V3 o, V3 id, float tmin,
-                    float tbest, float* tnear)
+// Slab test of one child box against [tmin, tbest]; returns the packed sort key: tnear bits with the child
+// slot in the two low bits, or 0xffffffff on a miss.  Padded so rounding can only add visits.
+VKR_DI uint32_t box_key(float minx, float miny, float minz, float maxx, float maxy, float maxz, V3 o, V3 id,
+                        float tmin, float tbest_pad, uint32_t slot)
 {
     float t0 = (minx - o.x) * id.x, t1 = (maxx - o.x) * id.x;
     float tn = __builtin_fminf(t0, t1), tf = __builtin_fmaxf(t0, t1);
@@ -85,15 +98,23 @@ VKR_DI bool box_hit(float minx, float miny, float minz, float maxx, float maxy, 
     tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
     t0 = (minz - o.z) * id.z; t1 = (maxz - o.z) * id.z;
     tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1)); tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
-    tn = __builtin_fmaxf(tn, tmin); tf = __builtin_fminf(tf, tbest);
-    *tnear = tn;
-    return tn * 0.999999f <= tf * 1.000001f;
+    tn = __builtin_fmaxf(tn, tmin);
+    tf = __builtin_fminf(tf * 1.000001f, tbest_pad);
+    // tn >= tmin >= 0: its bit pattern orders like an unsigned integer; clearing two bits only lowers it
+    uint32_t key = (f2u(tn * 0.999999f) & ~3u) | slot;
+    return (tn * 0.999999f <= tf) ? key : 0xffffffffu;
+}
+
+VKR_DI void cswap(uint32_t& a, uint32_t& b)
+{
+    uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
 }
 
 // MODE Q_AO      : closest committed hit, candidates filtered by class / alpha test (queryAoClosestHit)
 // MODE Q_SHADOW  : any hit, every triangle occludes (gl_RayFlagsOpaqueEXT|TerminateOnFirstHit, pbr.frag:199-215)
 // MODE Q_PRIMARY : as Q_AO, ties in t resolved towards the lower flat triangle id (G-buffer producer)
-// `stack` points at this lane's column of the block's LDS stack: entry k at stack[k * VKR_TRACE_BLOCK].
+// `stack` points at this lane's column of the block's LDS stack: entry k = {stack[(2k)*B], stack[(2k+1)*B]}.
 template <int MODE, bool STATS>
 __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, HitDev* hit,
                                          uint32_t* stack, TraceCounters* cnt)
@@ -104,78 +125,97 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
     bool found = false;
     if (sc.tri_count == 0) return false;
 
-    V3 id = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    uint32_t spill[VKR_MAX_STACK - VKR_LDS_STACK];
+    const V3 id = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    uint2 spill[VKR_MAX_STACK - VKR_LDS_STACK];
     int sp = 0;
-    int node = 0;
+    int cur = 0;  // root
+    constexpr int B = VKR_TRACE_BLOCK;
 
-    auto test_leaf = [&](int child) -> bool {
-        uint32_t ti = (uint32_t)(~child);
-        const float4* tp = sc.tris + (size_t)ti * 3;
-        float4 a = tp[0], b = tp[1], c = tp[2];
-        if (STATS) cnt->tris++;
-        V3 v0 = V3{a.x, a.y, a.z}, e1 = V3{b.x, b.y, b.z}, e2 = V3{c.x, c.y, c.z};
-        V3 pvec = cross3(d, e2);
-        float det = dot3(e1, pvec);
-        if (det == 0.0f) return false;
-        float inv = 1.0f / det;
-        V3 tvec = o - v0;
-        float u = dot3(tvec, pvec) * inv;
-        if (!(u >= 0.0f && u <= 1.0f)) return false;
-        V3 qvec = cross3(tvec, e1);
-        float v = dot3(d, qvec) * inv;
-        if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-        float t = dot3(e2, qvec) * inv;
-        if (!(t > tmin)) return false;
-        uint32_t flat = f2u(c.w);
-        if (MODE == Q_PRIMARY) {
-            if (!(t < tbest || (t == tbest && flat < best_flat))) return false;
-        } else {
-            if (!(t < tbest)) return false;
+    auto push = [&](uint32_t key, uint32_t ref) {
+        if (sp < VKR_LDS_STACK) { stack[(2 * sp) * B] = key; stack[(2 * sp + 1) * B] = ref; }
+        else spill[sp - VKR_LDS_STACK] = make_uint2(key, ref);
+        ++sp;
+    };
+    // pop the next entry still in front of the closest hit; false when the stack is exhausted
+    auto pop = [&]() -> bool {
+        while (sp > 0) {
+            --sp;
+            uint32_t key, ref;
+            if (sp < VKR_LDS_STACK) { key = stack[(2 * sp) * B]; ref = stack[(2 * sp + 1) * B]; }
+            else { uint2 e = spill[sp - VKR_LDS_STACK]; key = e.x; ref = e.y; }
+            if (u2f(key & ~3u) <= tbest * 1.000001f) { cur = (int)ref; return true; }
         }
-        if (MODE != Q_SHADOW) {
-            uint32_t mw = f2u(a.w);
-            uint32_t cls = mw >> 28;
-            if (cls == 1u) return false;
-            if (cls == 2u && !alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), u, v)) return false;
-        }
-        tbest = t; best_flat = flat; best_tri = ti; bu = u; bv = v; found = true;
-        return true;
+        return false;
     };
 
-    while (true) {
-        const float4* np = sc.nodes + (size_t)node * 4;
-        float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-        if (STATS) cnt->nodes++;
-        int left = (int)f2u(q3.x), right = (int)f2u(q3.y);
-        float tnl, tnr;
-        bool hl = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, tmin, tbest, &tnl);
-        if (hl && left < 0) {
-            bool h = test_leaf(left);
-            if (MODE == Q_SHADOW && h) break;
-            hl = false;
+    bool alive = true;
+    while (alive) {
+        // ---- internal nodes: descend until this lane holds a leaf (or runs out of work)
+        while (cur >= 0) {
+            const float4* np = sc.nodes + (size_t)cur * 8;
+            float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5], ch = np[6];
+            if (STATS) { cnt->nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt->wave_node_iters++; }
+            const float tb = tbest * 1.000001f;
+            uint32_t k0 = box_key(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, o, id, tmin, tb, 0u);
+            uint32_t k1 = box_key(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, o, id, tmin, tb, 1u);
+            uint32_t k2 = box_key(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, o, id, tmin, tb, 2u);
+            uint32_t k3 = box_key(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, o, id, tmin, tb, 3u);
+            cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);  // ascending
+            auto ref_of = [&](uint32_t key) -> uint32_t {
+                uint32_t s = key & 3u;
+                float r = s == 0u ? ch.x : (s == 1u ? ch.y : (s == 2u ? ch.z : ch.w));
+                return f2u(r);
+            };
+            if (k0 == 0xffffffffu) {           // nothing hit
+                if (!pop()) { alive = false; break; }
+                continue;
+            }
+            if (k3 != 0xffffffffu) push(k3, ref_of(k3));
+            if (k2 != 0xffffffffu) push(k2, ref_of(k2));
+            if (k1 != 0xffffffffu) push(k1, ref_of(k1));
+            cur = (int)ref_of(k0);
         }
-        bool hr = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, tmin, tbest, &tnr);
-        if (hr && right < 0) {
-            bool h = test_leaf(right);
-            if (MODE == Q_SHADOW && h) break;
-            hr = false;
-        }
-        if (hl && hr) {
-            int nearc = left, farc = right;
-            if (tnr < tnl) { nearc = right; farc = left; }
-            if (sp < VKR_LDS_STACK) stack[sp * VKR_TRACE_BLOCK] = (uint32_t)farc;
-            else spill[sp - VKR_LDS_STACK] = (uint32_t)farc;
-            ++sp;
-            node = nearc;
-        } else if (hl) {
-            node = left;
-        } else if (hr) {
-            node = right;
-        } else {
-            if (sp == 0) break;
-            --sp;
-            node = (int)((sp < VKR_LDS_STACK) ? stack[sp * VKR_TRACE_BLOCK] : spill[sp - VKR_LDS_STACK]);
+        if (!alive) break;
+        // ---- leaf
+        {
+            uint32_t x = (uint32_t)(~cur);
+            uint32_t first = x & 0x0fffffffu, count = ((x >> 28) & 7u) + 1u;
+            bool stop = false;
+            for (uint32_t k = 0; k < count; ++k) {
+                uint32_t ti = first + k;
+                const float4* tp = sc.tris + (size_t)ti * 3;
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                if (STATS) { cnt->tris++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt->wave_tri_iters++; }
+                V3 v0 = V3{a.x, a.y, a.z}, e1 = V3{b.x, b.y, b.z}, e2 = V3{c.x, c.y, c.z};
+                V3 pvec = cross3(d, e2);
+                float det = dot3(e1, pvec);
+                if (det == 0.0f) continue;
+                float inv = 1.0f / det;
+                V3 tvec = o - v0;
+                float u = dot3(tvec, pvec) * inv;
+                if (!(u >= 0.0f && u <= 1.0f)) continue;
+                V3 qvec = cross3(tvec, e1);
+                float v = dot3(d, qvec) * inv;
+                if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+                float t = dot3(e2, qvec) * inv;
+                if (!(t > tmin)) continue;
+                uint32_t flat = f2u(c.w);
+                if (MODE == Q_PRIMARY) {
+                    if (!(t < tbest || (t == tbest && flat < best_flat))) continue;
+                } else {
+                    if (!(t < tbest)) continue;
+                }
+                if (MODE != Q_SHADOW) {
+                    uint32_t mw = f2u(a.w);
+                    uint32_t cls = mw >> 28;
+                    if (cls == 1u) continue;
+                    if (cls == 2u && !alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), u, v)) continue;
+                }
+                tbest = t; best_flat = flat; best_tri = ti; bu = u; bv = v; found = true;
+                if (MODE == Q_SHADOW) { stop = true; break; }
+            }
+            if (stop) break;
+            if (!pop()) break;
         }
     }
     if (hit) { hit->t = tbest; hit->tri = best_tri; hit->u = bu; hit->v = bv; }

@@ -125,8 +125,8 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
         if ((e = c->d_ping[i].alloc(px)) != hipSuccess) return bail(VKR_ERR_OOM, "ping-pong image", e);
     }
     if ((e = c->d_nz.alloc(px)) != hipSuccess) return bail(VKR_ERR_OOM, "A-Trous operand", e);
-    if ((e = c->d_stats.alloc(4)) != hipSuccess) return bail(VKR_ERR_OOM, "counters", e);
-    if ((e = hipMemset(c->d_stats.p, 0, 32)) != hipSuccess) return bail(VKR_ERR_HIP, "hipMemset", e);
+    if ((e = c->d_stats.alloc(8)) != hipSuccess) return bail(VKR_ERR_OOM, "counters", e);
+    if ((e = hipMemset(c->d_stats.p, 0, 64)) != hipSuccess) return bail(VKR_ERR_HIP, "hipMemset", e);
     int rc = vkr_rtao_reset(c, nullptr);
     if (rc != VKR_OK) { g_create_error = c->err; vkr_destroy(c); return rc; }
     if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(VKR_ERR_HIP, "hipStreamSynchronize", e);
@@ -144,9 +144,11 @@ void vkr_destroy(vkr_ctx* c)
     c->d_inst_mesh.release(); c->d_inst_first_tri.release(); c->d_inst_xf.release();
     c->d_nodes.release(); c->d_tris.release(); c->d_perm.release(); c->d_leaf_parent.release();
     c->d_node_parent.release(); c->d_flags.release();
+    c->d_bin_child.release(); c->d_bin_range.release(); c->d_deposit.release(); c->d_node_box.release();
+    c->d_wide_ctl.release(); c->d_wide_bin.release();
     for (int i = 0; i < 2; ++i) { c->d_keys[i].release(); c->d_vals[i].release(); c->d_hist_img[i].release(); c->d_ping[i].release(); }
     c->d_hist.release(); c->d_digit_totals.release(); c->d_bounds.release(); c->d_height.release();
-    c->d_nz.release(); c->d_stats.release();
+    c->d_nz.release(); c->d_stats.release(); c->d_raybuf.release();
     delete c;
 }
 
@@ -276,7 +278,13 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     c->instance_count = s->instance_count;
     c->tri_count = (uint32_t)tri_total;
     const size_t n = c->tri_count ? c->tri_count : 1;
-    HIP_OR_FAIL(c, c->d_nodes.alloc(n * 4));
+    HIP_OR_FAIL(c, c->d_nodes.alloc(n * 8));
+    HIP_OR_FAIL(c, c->d_bin_child.alloc(n));
+    HIP_OR_FAIL(c, c->d_bin_range.alloc(n));
+    HIP_OR_FAIL(c, c->d_deposit.alloc(n * 8));
+    HIP_OR_FAIL(c, c->d_node_box.alloc(n * 2));
+    HIP_OR_FAIL(c, c->d_wide_ctl.alloc(4));
+    HIP_OR_FAIL(c, c->d_wide_bin.alloc(n));
     HIP_OR_FAIL(c, c->d_tris.alloc(n * 3));
     HIP_OR_FAIL(c, c->d_perm.alloc(n));
     HIP_OR_FAIL(c, c->d_leaf_parent.alloc(n));
@@ -295,9 +303,8 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     return VKR_OK;
 }
 
-static int finish_build(vkr_ctx* c, hipStream_t st)
+static int read_height_and_bounds(vkr_ctx* c, hipStream_t st)
 {
-    // height + bounds are tiny; reading them back makes the stack-depth contract checkable here
     BvhBounds b;
     uint32_t h = 0;
     HIP_OR_FAIL(c, hipMemcpyAsync(&h, c->d_height.p, 4, hipMemcpyDeviceToHost, st));
@@ -316,17 +323,28 @@ int vkr_bvh_build(vkr_ctx* c, void* stream)
     hipStream_t st = (hipStream_t)stream;
     c->has_bvh = false;
     c->bvh_height = 0;
+    c->wide_count = 0;
+    c->wide_levels = 0;
     if (c->tri_count == 0) { c->has_bvh = true; return VKR_OK; }
-    // 21 bits/axis; if the tree comes out deeper than the traversal stack (pathological duplicates), fall back
-    // to 10 bits/axis where the index tie-break bounds the height by 30 + log2(n).
+    // 21 bits/axis; if the wide tree comes out deeper than the traversal stack allows (pathological duplicate
+    // centroids), fall back to 10 bits/axis where the index tie-break bounds the height by 30 + log2(n).
     const uint32_t tries[2] = {21u, 10u};
     for (int t = 0; t < 2; ++t) {
         c->morton_bits = tries[t];
         HIP_OR_FAIL(c, bvh_build_launch(c, false, st));
-        if (int rc = finish_build(c, st)) return rc;
-        if (c->bvh_height <= (uint32_t)VKR_MAX_STACK) { c->has_bvh = true; return VKR_OK; }
+        // the binary height bounds the number of BFS levels of the collapse; it is one word
+        if (int rc = read_height_and_bounds(c, st)) return rc;
+        HIP_OR_FAIL(c, bvh_wide_launch(c, c->bvh_height, st));
+        uint32_t ctl[4] = {0, 0, 0, 0};
+        HIP_OR_FAIL(c, hipMemcpyAsync(ctl, c->d_wide_ctl.p, 16, hipMemcpyDeviceToHost, st));
+        HIP_OR_FAIL(c, hipStreamSynchronize(st));
+        c->wide_count = ctl[0];
+        c->wide_levels = ctl[3];
+        // near-first traversal defers at most 3 children per level
+        if (3u * c->wide_levels + 1u <= (uint32_t)VKR_MAX_STACK) { c->has_bvh = true; return VKR_OK; }
     }
-    return fail(c, VKR_ERR_LIMIT, "BVH height %u exceeds traversal stack %d", c->bvh_height, VKR_MAX_STACK);
+    return fail(c, VKR_ERR_LIMIT, "BVH depth %u levels exceeds the traversal stack (%d entries)", c->wide_levels,
+                VKR_MAX_STACK);
 }
 
 int vkr_bvh_refit(vkr_ctx* c, const vkr_instance* inst, uint32_t count, void* stream)
@@ -359,8 +377,9 @@ int vkr_bvh_info_get(vkr_ctx* c, vkr_bvh_info* out)
     if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
     if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "no BVH");
     out->triangle_count = c->tri_count;
-    out->node_count = c->tri_count > 1 ? c->tri_count - 1 : (c->tri_count == 1 ? 1 : 0);
-    out->height = c->bvh_height;
+    out->node_count = c->wide_count;
+    out->height = c->wide_levels;
+    out->binary_height = c->bvh_height;
     out->morton_bits = c->morton_bits;
     for (int k = 0; k < 3; ++k) { out->bounds_min[k] = c->bounds_min[k]; out->bounds_max[k] = c->bounds_max[k]; }
     return VKR_OK;
@@ -372,8 +391,8 @@ int vkr_bvh_download(vkr_ctx* c, float* nodes, float* tris)
     if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "no BVH");
     if (int rc = set_device(c)) return rc;
     HIP_OR_FAIL(c, hipDeviceSynchronize());
-    size_t nn = c->tri_count > 1 ? c->tri_count - 1 : (c->tri_count == 1 ? 1 : 0);
-    if (nodes && nn) HIP_OR_FAIL(c, hipMemcpy(nodes, c->d_nodes.p, nn * 64, hipMemcpyDeviceToHost));
+    size_t nn = c->wide_count;
+    if (nodes && nn) HIP_OR_FAIL(c, hipMemcpy(nodes, c->d_nodes.p, nn * 128, hipMemcpyDeviceToHost));
     if (tris && c->tri_count) HIP_OR_FAIL(c, hipMemcpy(tris, c->d_tris.p, (size_t)c->tri_count * 48, hipMemcpyDeviceToHost));
     return VKR_OK;
 }
@@ -549,10 +568,11 @@ int vkr_trace_stats_get(vkr_ctx* c, vkr_trace_stats* out, int reset)
     if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
     if (int rc = set_device(c)) return rc;
     HIP_OR_FAIL(c, hipDeviceSynchronize());
-    unsigned long long h[3];
-    HIP_OR_FAIL(c, hipMemcpy(h, c->d_stats.p, 24, hipMemcpyDeviceToHost));
+    unsigned long long h[5];
+    HIP_OR_FAIL(c, hipMemcpy(h, c->d_stats.p, 40, hipMemcpyDeviceToHost));
     out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
-    if (reset) HIP_OR_FAIL(c, hipMemset(c->d_stats.p, 0, 32));
+    out->wave_node_iters = h[3]; out->wave_tri_iters = h[4];
+    if (reset) HIP_OR_FAIL(c, hipMemset(c->d_stats.p, 0, 64));
     return VKR_OK;
 }
 
