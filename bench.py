@@ -121,6 +121,9 @@ def main():
     frames = K + Wu
 
     scene = make_scene(scene_kind)
+    if os.environ.get("VKR_BENCH_ALL_OPAQUE"):      # experiment switch: cost of the MASK/BLEND candidate path
+        for m in scene.materials:
+            m.alpha_mode = 0
     ctx = Context(W, H, local_rank)
     rt = RayTracingContext(ctx)
     t0 = time.perf_counter()
@@ -236,7 +239,8 @@ def main():
                            "launch_ms": trace_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                            "nodes_per_ray": st.nodes_visited / max(1, ao_rays), "tris_per_ray": st.tris_tested / max(1, ao_rays),
                            "lane_util_node_loop": st.nodes_visited / max(1, 64 * st.wave_node_iters),
-                           "lane_util_tri_loop": st.tris_tested / max(1, 64 * st.wave_tri_iters)}
+                           "lane_util_tri_loop": st.tris_tested / max(1, 64 * st.wave_tri_iters),
+                           "overflow_tiles_per_frame": st.overflow_tiles / K}
         atrous_bytes = 14.0 * px * iters
         out["kernels"] = {"trace_ms": trace_ms, "atrous_total_ms": float(np.mean(t_atrous)), "upsample_ms": float(np.mean(t_up)),
                           "ao_mrays_per_s_kernel": ao_rays / K / (trace_ms * 1e-3) / 1e6,

@@ -244,6 +244,7 @@ typedef struct vkr_trace_stats {
     uint64_t tris_tested;   /* ray/triangle tests                           */
     uint64_t wave_node_iters; /* node-loop iterations counted once per wave (lane utilisation = nodes_visited / (64*this)) */
     uint64_t wave_tri_iters;  /* triangle-loop iterations counted once per wave */
+    uint64_t overflow_tiles;  /* 8x8 tiles handed to the generic kernel because a short stack overflowed */
 } vkr_trace_stats;
 /* Enable (1) / disable (0) traversal counters for subsequent AO traces (slower kernel variant), and read
  * them back (synchronises).  Feeds bench.py's algorithmic-bytes figure. */

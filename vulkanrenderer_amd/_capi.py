@@ -51,7 +51,7 @@ class RtaoFrameIO(C.Structure):
 
 class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_node_iters", C.c_uint64),
-                ("wave_tri_iters", C.c_uint64)]
+                ("wave_tri_iters", C.c_uint64), ("overflow_tiles", C.c_uint64)]
 
 
 # every symbol include/vkr_rt.h declares: name -> (restype, argtypes)

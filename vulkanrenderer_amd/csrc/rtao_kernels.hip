@@ -71,29 +71,6 @@ VKR_DI V3 offsetRay(V3 p, V3 n)  // :112-123
               (__builtin_fabsf(p.z) < ORIGIN_EPS) ? (p.z + FLOAT_SCALE * n.z) : pz};
 }
 
-// :184-213 over :125-182
-template <bool STATS>
-VKR_DI float traceAoRay(const SceneDev& sc, V3 origin, V3 dir, float tMin, float tMax, uint32_t* stack,
-                        TraceCounters* cnt, uint32_t* nrays, int* occluded)
-{
-    *occluded = 0;
-    HitDev h;
-    if (STATS) (*nrays)++;
-    if (!traverse<Q_AO, STATS>(sc, origin, dir, tMin, tMax, &h, stack, cnt)) return 1.0f;
-    float t = h.t;
-    if (t <= tMin * 1.5f) {
-        float retryAdvance = gmax(tMin * 2.0f, 2e-4f);
-        if (STATS) (*nrays)++;
-        if (!traverse<Q_AO, STATS>(sc, origin + dir * retryAdvance, dir, gmax(tMin, 1e-4f), tMax, &h, stack, cnt))
-            return 1.0f;
-        t = h.t + retryAdvance;
-    }
-    if (t <= tMin * 1.5f) return 1.0f;
-    *occluded = 1;
-    float x = gclamp((t - tMin) / gmax(tMax - tMin, 1e-3f), 0.0f, 1.0f);
-    return pow3(x);
-}
-
 VKR_DI bool computePrevUv(const float* prevViewProj, V3 worldPos, V2* prevUv)  // :215-228
 {
     float c[4];
@@ -105,14 +82,6 @@ VKR_DI bool computePrevUv(const float* prevViewProj, V3 worldPos, V2* prevUv)  /
     return true;
 }
 
-// XCD-aware block order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
-// run of tiles -> neighbouring tiles (which walk the same BVH subtrees) share one L2.  Bijective for any n.
-VKR_DI uint32_t xcd_remap(uint32_t b, uint32_t n)
-{
-    uint32_t q = n / 8u, r = n % 8u, x = b % 8u, s = b / 8u;
-    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + s;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K1: trace + temporal (:230-472).  One wave per workgroup, one 8x8 pixel tile per wave (the reference's
 // workgroup shape, :6): a tile's cost varies a lot (sky vs foliage), and single-wave workgroups release their CU
@@ -122,24 +91,202 @@ VKR_DI uint32_t xcd_remap(uint32_t b, uint32_t n)
 //      GENERATED into the wave's slice of a ray buffer (2 x float4 per ray, compacted over valid pixels);
 //   2. per ray (lane = worker): the 64 lanes pull rays from that slice as they become free (the tile's
 //      rays/px * 64 rays form the wave's work list), so a lane whose ray ends early -- or whose own pixel is sky --
-//      does not idle until the slowest ray of the wave finishes; each lane runs the traversal state machine of
-//      traverse.hpp (while-while, LDS short stack) incl. the self-hit retry of traceAoRay (:193-200) and
-//      stores visibility (sign bit = "a hit contributed occlusion") in the slice's result area;
+//      does not idle until the slowest ray of the wave finishes; each lane runs a one-step-per-iteration traversal
+//      state machine (node step or triangle step, voted per wave; LDS-only short stack) incl. the self-hit
+//      retry of traceAoRay (:193-200) and stores visibility (sign bit = "a hit contributed occlusion") in the
+//      slice's result area;
 //   3. per pixel again: visibility summed in ray order (:431-433) and the temporal accumulation (:440-471).
 // The ray slice is written and read by the same wave (workgroup-scope fences = s_waitcnt only: one CU, one L1).
+// The short stack spills to per-lane scratch beyond VKR_LDS_STACK entries; the spill path is entered only by a
+// lane about to run past the LDS part, so it stays out of the common instruction stream.
 // ---------------------------------------------------------------------------------------------
 constexpr int CUR_DONE = (int)0x80000000;
+constexpr int K1_BLOCK = 64;
 
 VKR_DI uint32_t ray_slice_float4s(int rayCount) { return (uint32_t)rayCount * 64u * 2u + (uint32_t)rayCount * 16u; }
 
-constexpr int K1_BLOCK = 64;
+struct PixelCtx {
+    bool valid;            // this pixel casts rays
+    V3 worldPos, geomNormal, origin, tT, tB;
+    float viewZ, bias, footprint, radius, tMin, cs, sn;
+};
+
+// main() :237-400 for one pixel: early-outs store their value themselves and leave valid = false.
+VKR_DI void setup_pixel(const FrameParams& fp, const Img16& depth, uint16_t* histCurr, uint32_t* hitMask, int px, int py,
+                        PixelCtx& c)
+{
+    const int W = fp.W, H = fp.H;
+    const size_t o = (size_t)py * W + px;
+    c.valid = false;
+    c.worldPos = v3(0, 0, 0); c.geomNormal = v3(0, 1, 0); c.origin = v3(0, 0, 0); c.tT = v3(0, 0, 0); c.tB = v3(0, 0, 0);
+    c.viewZ = 0.0f; c.bias = 0.0f; c.footprint = 0.0f; c.radius = 0.0f; c.tMin = 0.0f; c.cs = 1.0f; c.sn = 0.0f;
+    if (hitMask) hitMask[o] = 0;
+    float u = gclamp(((float)px + 0.5f) / (float)W, 0.0f, 1.0f);                // :237-238
+    float v = gclamp(((float)py + 0.5f) / (float)H, 0.0f, 1.0f);
+    float linearViewZ = tex_nearest_r(depth, u, v);                             // :239
+    if (linearViewZ <= 1e-6f) { histCurr[o] = float_to_half(1.0f); return; }    // :240-243
+
+    V3 viewPos = reconstructViewPosFromLinearZ(fp.invProj, u, v, linearViewZ);  // :247
+    const float viewZ = linearViewZ;
+    c.viewZ = viewZ;
+    float wp[4];
+    mul_m4_v4(fp.invView, viewPos.x, viewPos.y, viewPos.z, 1.0f, wp);           // :249
+    c.worldPos = V3{wp[0], wp[1], wp[2]};
+    const float baseRadius = fp.baseRadius, baseBias = fp.baseBias;             // :253-254
+
+    float texelX = 1.0f / (float)W, texelY = 1.0f / (float)H;                   // :257
+    float discontinuityAbsZ = gmax(0.02f, baseRadius * 0.25f);                  // :260
+    const float DISCONTINUITY_REL_Z = 0.015f;
+
+    float uXp = u + texelX, uXm = u - texelX, vYp = v + texelY, vYm = v - texelY;  // :263-266
+    float depthXp = tex_nearest_r(depth, uXp, v);                               // :268-271
+    float depthXm = tex_nearest_r(depth, uXm, v);
+    float depthYp = tex_nearest_r(depth, u, vYp);
+    float depthYm = tex_nearest_r(depth, u, vYm);
+    depthXp = (depthXp <= 1e-6f) ? linearViewZ : depthXp;                       // :272-275
+    depthXm = (depthXm <= 1e-6f) ? linearViewZ : depthXm;
+    depthYp = (depthYp <= 1e-6f) ? linearViewZ : depthYp;
+    depthYm = (depthYm <= 1e-6f) ? linearViewZ : depthYm;
+
+    V3 viewPosXp = reconstructViewPosFromLinearZ(fp.invProj, uXp, v, depthXp);  // :277-280
+    V3 viewPosXm = reconstructViewPosFromLinearZ(fp.invProj, uXm, v, depthXm);
+    V3 viewPosYp = reconstructViewPosFromLinearZ(fp.invProj, u, vYp, depthYp);
+    V3 viewPosYm = reconstructViewPosFromLinearZ(fp.invProj, u, vYm, depthYm);
+
+    float zXp = -viewPosXp.z, zXm = -viewPosXm.z, zYp = -viewPosYp.z, zYm = -viewPosYm.z;  // :282-285
+    float dXp = __builtin_fabsf(zXp - viewZ), dXm = __builtin_fabsf(zXm - viewZ);          // :287-290
+    float dYp = __builtin_fabsf(zYp - viewZ), dYm = __builtin_fabsf(zYm - viewZ);
+    float zden = gmax(viewZ, 1e-3f);
+    float rXp = dXp / zden, rXm = dXm / zden, rYp = dYp / zden, rYm = dYm / zden;          // :292-295
+    bool okXp = (rXp <= DISCONTINUITY_REL_Z) && (dXp <= discontinuityAbsZ);                // :297-300
+    bool okXm = (rXm <= DISCONTINUITY_REL_Z) && (dXm <= discontinuityAbsZ);
+    bool okYp = (rYp <= DISCONTINUITY_REL_Z) && (dYp <= discontinuityAbsZ);
+    bool okYm = (rYm <= DISCONTINUITY_REL_Z) && (dYm <= discontinuityAbsZ);
+
+    V3 viewPosX = viewPos, viewPosY = viewPos;                                  // :302-317
+    if (okXp && okXm) viewPosX = (dXp <= dXm) ? viewPosXp : viewPosXm;
+    else if (okXp) viewPosX = viewPosXp;
+    else if (okXm) viewPosX = viewPosXm;
+    if (okYp && okYm) viewPosY = (dYp <= dYm) ? viewPosYp : viewPosYm;
+    else if (okYp) viewPosY = viewPosYp;
+    else if (okYm) viewPosY = viewPosYm;
+
+    V3 viewDx = viewPosX - viewPos, viewDy = viewPosY - viewPos;                // :319-321
+    const float footprint = gmax(length3(viewDx), length3(viewDy));
+    c.footprint = footprint;
+
+    V3 bestViewN = v3(0, 0, 0);                                                 // :326-351
+    float bestScore = 1e30f;
+    {
+        const bool ok[4] = {okXp && okYp, okXp && okYm, okXm && okYp, okXm && okYm};
+        const V3 ea[4] = {viewPosYp - viewPos, viewPosXp - viewPos, viewPosYp - viewPos, viewPosXm - viewPos};
+        const V3 eb[4] = {viewPosXp - viewPos, viewPosYm - viewPos, viewPosXm - viewPos, viewPosYm - viewPos};
+        const float sc4[4] = {dXp + dYp, dXp + dYm, dXm + dYp, dXm + dYm};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            V3 n = cross3(ea[k], eb[k]);
+            float n2 = dot3(n, n);
+            if (ok[k] && n2 > 1e-14f && sc4[k] < bestScore) { bestScore = sc4[k]; bestViewN = n * inversesqrt(n2); }
+        }
+    }
+    V3 geomNormal = v3(0, 1, 0);                                                // :353-359
+    if (bestScore < 1e29f) geomNormal = normalize3(mul_m3_v3(fp.invView, bestViewN));
+    V3 camPos = V3{fp.camPos[0], fp.camPos[1], fp.camPos[2]};
+    if (dot3(geomNormal, camPos - c.worldPos) < 0.0f) geomNormal = neg(geomNormal);  // :360-362
+    c.geomNormal = geomNormal;
+
+    float biasFromFootprint = footprint * 0.05f;                                // :365
+    float biasMax = gmax(baseBias, gmin(baseRadius * 0.02f, 0.03f));            // :367
+    c.bias = gclamp(gmax(baseBias, biasFromFootprint), baseBias, biasMax);      // :368
+    float radiusScale = gclamp(sqrt_(gmax(footprint, 1e-4f) / 0.03f), 1.0f, 1.6f);  // :371
+    c.radius = baseRadius * radiusScale;                                        // :372
+
+    c.origin = offsetRay(c.worldPos, geomNormal);                               // :375
+    buildTbn(geomNormal, &c.tT, &c.tB);                                         // :376
+    c.tMin = gmax(1e-4f, c.bias * 0.25f);                                       // :377
+
+    if (fp.debugMode == 10u) { histCurr[o] = float_to_half(gclamp(c.bias / 0.05f, 0.0f, 1.0f)); return; }       // :381-385
+    if (fp.debugMode == 11u) { histCurr[o] = float_to_half(gclamp(footprint / 0.05f, 0.0f, 1.0f)); return; }    // :386-390
+
+    float frameTerm = (fp.rayCount >= 4) ? (fp.frameIndex * 131.0f) : 0.0f;     // :395
+    float seedBase = ((float)px * 1.0f + (float)py * 57.0f) + frameTerm;        // :396
+    float angle = hash11(seedBase) * 6.28318530718f;                            // :397
+    det_sincos(angle, &c.sn, &c.cs);                                            // :398-399
+    c.valid = true;
+}
+
+// ray i of the pixel (:404-429)
+VKR_DI void make_ray(const PixelCtx& c, int rayCount, int i, V3* rayOrigin, V3* rayDir, float* tMinRay)
+{
+    float xix = (float)i / gmax((float)rayCount, 1.0f);                         // hammersley :79-82
+    float xiy = radicalInverseVdC((uint32_t)i);
+    float ax = xix - 0.5f, ay = xiy - 0.5f;
+    float rx = (c.cs * ax + c.sn * ay) + 0.5f;                                  // rot*(xi-0.5)+0.5, :400,405
+    float ry = (-c.sn * ax + c.cs * ay) + 0.5f;
+    rx = gclamp(rx, 0.0f, 1.0f);                                                // :406
+    ry = gclamp(ry, 0.0f, 1.0f);
+    float phi = 6.28318530718f * rx;                                            // :408
+    float cosTheta = sqrt_(1.0f - ry), sinTheta = sqrt_(ry);                    // :409-410
+    float sphi, cphi;
+    det_sincos(phi, &sphi, &cphi);
+    V3 l = V3{cphi * sinTheta, sphi * sinTheta, cosTheta};                      // :411
+    const V3 tT = c.tT, tB = c.tB, n = c.geomNormal;
+    V3 rd = V3{(tT.x * l.x + tB.x * l.y) + n.x * l.z, (tT.y * l.x + tB.y * l.y) + n.y * l.z,
+               (tT.z * l.x + tB.z * l.y) + n.z * l.z};
+    V3 d = normalize3(rd);                                                      // :412
+    float nd = gclamp(dot3(n, d), 0.0f, 1.0f);                                  // :418
+    float grazing = 1.0f - nd;
+    float slopeScaled = gmax(c.bias * 0.5f, c.footprint * 0.02f);               // :421
+    float dirOffset = slopeScaled * (0.15f + (1.5f * grazing) * grazing);       // :422
+    *rayOrigin = c.origin + d * dirOffset;                                      // :423
+    float t = c.tMin;                                                           // :427-429
+    t = gmax(t, dirOffset * 2.5f);
+    t = gmax(t, ((c.radius * 0.03f) * grazing) * grazing);
+    *tMinRay = t;
+    *rayDir = d;
+}
+
+// :433-471 for one pixel, given the summed visibility and the per-ray occlusion bits
+VKR_DI void resolve_pixel(const FrameParams& fp, const Img16& depth, const Img16& histPrev, uint16_t* histCurr,
+                          uint32_t* hitMask, int px, int py, const PixelCtx& c, float visibility, uint32_t mask)
+{
+    const int W = fp.W, H = fp.H, rayCount = fp.rayCount;
+    const size_t o = (size_t)py * W + px;
+    const float viewZ = c.viewZ;
+    if (hitMask) hitMask[o] = mask;
+    float current = visibility / (float)rayCount;                               // :433
+    if (fp.debugMode == 12u) { histCurr[o] = float_to_half(gclamp(current, 0.0f, 1.0f)); return; }  // :435-438
+
+    float hu = ((float)px + 0.5f) / (float)W, hv = ((float)py + 0.5f) / (float)H;  // :440
+    V2 prevUv = V2{hu, hv};
+    bool hasPrev = computePrevUv(fp.prevViewProj, c.worldPos, &prevUv);         // :442
+    float su = hasPrev ? prevUv.x : hu, sv = hasPrev ? prevUv.y : hv;
+    float history = tex_linear_r(histPrev, su, sv);                             // :443
+    float prevViewZ = tex_nearest_r(depth, su, sv);                             // :444
+    if (prevViewZ <= 1e-6f) prevViewZ = viewZ;                                  // :445-447
+    float depthDiff = __builtin_fabsf(prevViewZ - viewZ) / gmax(viewZ, 1e-3f);  // :449
+    float temporalAlpha = gclamp(fp.temporalAlphaRaw, 0.0f, 0.99f);             // :450
+    float baseThreshold = gmax(fp.disocclusionRaw, 0.0f);                       // :452
+    float noiseTerm = 0.6f / sqrt_((float)rayCount);                            // :453
+    float disocclusionThreshold = gclamp(baseThreshold + noiseTerm, 0.0f, 1.5f);  // :454
+    float variance = gmax(current * (1.0f - current), 0.0f) / (float)rayCount;  // :457
+    float sigma = sqrt_(variance);                                              // :458
+    float clampK = 2.5f;
+    float historyClamped = gclamp(history, current - clampK * sigma, current + clampK * sigma);  // :460
+    float delta = __builtin_fabsf(current - historyClamped);                    // :462
+    float rejectDelta = smoothstep_(disocclusionThreshold, disocclusionThreshold * 2.0f + 1e-5f, delta);  // :463
+    float rejectDepth = smoothstep_(0.02f, 0.15f, depthDiff);                   // :466
+    float reject = gmax(rejectDelta, rejectDepth);                              // :467
+    float historyWeight = (fp.frameIndex < 0.5f) ? 0.0f : (temporalAlpha * (1.0f - reject));  // :468
+    float accum = mixf(current, historyClamped, historyWeight);                 // :469
+    histCurr[o] = float_to_half(accum);                                         // :471
+}
 
 template <bool STATS>
 __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp, const uint16_t* depthP,
-                                                           const uint16_t* histPrevP, uint16_t* histCurr,
-                                                           uint32_t* hitMask, int y0, int y1, uint32_t tiles_x,
-                                                           uint32_t n_tiles, float4* rayBuf,
-                                                           unsigned long long* stats)
+                                                    const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
+                                                    int y0, int y1, uint32_t tiles_x, float4* rayBuf,
+                                                    unsigned long long* stats)
 {
     __shared__ uint32_t s_stack[2 * VKR_LDS_STACK * K1_BLOCK];
     __shared__ float s_radius[K1_BLOCK];
@@ -151,141 +298,28 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
     const int px = (int)(tile % tiles_x) * 8 + (lane & 7);
     const int py = y0 + (int)(tile / tiles_x) * 8 + (lane >> 3);
     const int W = fp.W, H = fp.H;
-    const bool inside = (px < W && py < y1);                                    // :233-235
     const Img16 depth{depthP, W, H}, histPrev{histPrevP, W, H};
-    const size_t o = (size_t)py * W + px;
-    const uint32_t debugMode = fp.debugMode;                                    // :250
     const int rayCount = fp.rayCount;                                           // :252
     float4* slice = rayBuf + (size_t)blockIdx.x * ray_slice_float4s(rayCount);
     float* results = (float*)(slice + (size_t)rayCount * 128u);                 // [ray i][pixel lane]
 
     // ------------------------------------------------------------------ phase 1: per pixel
-    bool valid = false;            // this lane's pixel casts rays
-    V3 worldPos = v3(0, 0, 0), geomNormal = v3(0, 1, 0), origin = v3(0, 0, 0), tT = v3(0, 0, 0), tB = v3(0, 0, 0);
-    float viewZ = 0.0f, bias = 0.0f, footprint = 0.0f, radius = 0.0f, tMin = 0.0f, cs = 1.0f, sn = 0.0f;
-    if (inside) {
-        if (hitMask) hitMask[o] = 0;
-        float u = gclamp(((float)px + 0.5f) / (float)W, 0.0f, 1.0f);            // :237-238
-        float v = gclamp(((float)py + 0.5f) / (float)H, 0.0f, 1.0f);
-        float linearViewZ = tex_nearest_r(depth, u, v);                         // :239
-        if (linearViewZ <= 1e-6f) {
-            histCurr[o] = float_to_half(1.0f);                                  // :240-243
-        } else {
-            V3 viewPos = reconstructViewPosFromLinearZ(fp.invProj, u, v, linearViewZ);  // :247
-            viewZ = linearViewZ;
-            float wp[4];
-            mul_m4_v4(fp.invView, viewPos.x, viewPos.y, viewPos.z, 1.0f, wp);   // :249
-            worldPos = V3{wp[0], wp[1], wp[2]};
-            const float baseRadius = fp.baseRadius, baseBias = fp.baseBias;     // :253-254
-
-            float texelX = 1.0f / (float)W, texelY = 1.0f / (float)H;           // :257
-            float discontinuityAbsZ = gmax(0.02f, baseRadius * 0.25f);          // :260
-            const float DISCONTINUITY_REL_Z = 0.015f;
-
-            float uXp = u + texelX, uXm = u - texelX, vYp = v + texelY, vYm = v - texelY;  // :263-266
-            float depthXp = tex_nearest_r(depth, uXp, v);                       // :268-271
-            float depthXm = tex_nearest_r(depth, uXm, v);
-            float depthYp = tex_nearest_r(depth, u, vYp);
-            float depthYm = tex_nearest_r(depth, u, vYm);
-            depthXp = (depthXp <= 1e-6f) ? linearViewZ : depthXp;               // :272-275
-            depthXm = (depthXm <= 1e-6f) ? linearViewZ : depthXm;
-            depthYp = (depthYp <= 1e-6f) ? linearViewZ : depthYp;
-            depthYm = (depthYm <= 1e-6f) ? linearViewZ : depthYm;
-
-            V3 viewPosXp = reconstructViewPosFromLinearZ(fp.invProj, uXp, v, depthXp);  // :277-280
-            V3 viewPosXm = reconstructViewPosFromLinearZ(fp.invProj, uXm, v, depthXm);
-            V3 viewPosYp = reconstructViewPosFromLinearZ(fp.invProj, u, vYp, depthYp);
-            V3 viewPosYm = reconstructViewPosFromLinearZ(fp.invProj, u, vYm, depthYm);
-
-            float zXp = -viewPosXp.z, zXm = -viewPosXm.z, zYp = -viewPosYp.z, zYm = -viewPosYm.z;  // :282-285
-            float dXp = __builtin_fabsf(zXp - viewZ), dXm = __builtin_fabsf(zXm - viewZ);          // :287-290
-            float dYp = __builtin_fabsf(zYp - viewZ), dYm = __builtin_fabsf(zYm - viewZ);
-            float zden = gmax(viewZ, 1e-3f);
-            float rXp = dXp / zden, rXm = dXm / zden, rYp = dYp / zden, rYm = dYm / zden;          // :292-295
-            bool okXp = (rXp <= DISCONTINUITY_REL_Z) && (dXp <= discontinuityAbsZ);                // :297-300
-            bool okXm = (rXm <= DISCONTINUITY_REL_Z) && (dXm <= discontinuityAbsZ);
-            bool okYp = (rYp <= DISCONTINUITY_REL_Z) && (dYp <= discontinuityAbsZ);
-            bool okYm = (rYm <= DISCONTINUITY_REL_Z) && (dYm <= discontinuityAbsZ);
-
-            V3 viewPosX = viewPos, viewPosY = viewPos;                          // :302-317
-            if (okXp && okXm) viewPosX = (dXp <= dXm) ? viewPosXp : viewPosXm;
-            else if (okXp) viewPosX = viewPosXp;
-            else if (okXm) viewPosX = viewPosXm;
-            if (okYp && okYm) viewPosY = (dYp <= dYm) ? viewPosYp : viewPosYm;
-            else if (okYp) viewPosY = viewPosYp;
-            else if (okYm) viewPosY = viewPosYm;
-
-            V3 viewDx = viewPosX - viewPos, viewDy = viewPosY - viewPos;        // :319-321
-            footprint = gmax(length3(viewDx), length3(viewDy));
-
-            V3 bestViewN = v3(0, 0, 0);                                         // :326-351
-            float bestScore = 1e30f;
-            {
-                const bool ok[4] = {okXp && okYp, okXp && okYm, okXm && okYp, okXm && okYm};
-                const V3 ea[4] = {viewPosYp - viewPos, viewPosXp - viewPos, viewPosYp - viewPos, viewPosXm - viewPos};
-                const V3 eb[4] = {viewPosXp - viewPos, viewPosYm - viewPos, viewPosXm - viewPos, viewPosYm - viewPos};
-                const float sc4[4] = {dXp + dYp, dXp + dYm, dXm + dYp, dXm + dYm};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    V3 n = cross3(ea[k], eb[k]);
-                    float n2 = dot3(n, n);
-                    if (ok[k] && n2 > 1e-14f && sc4[k] < bestScore) { bestScore = sc4[k]; bestViewN = n * inversesqrt(n2); }
-                }
-            }
-            if (bestScore < 1e29f) geomNormal = normalize3(mul_m3_v3(fp.invView, bestViewN));     // :353-359
-            V3 camPos = V3{fp.camPos[0], fp.camPos[1], fp.camPos[2]};
-            if (dot3(geomNormal, camPos - worldPos) < 0.0f) geomNormal = neg(geomNormal);          // :360-362
-
-            float biasFromFootprint = footprint * 0.05f;                        // :365
-            float biasMax = gmax(baseBias, gmin(baseRadius * 0.02f, 0.03f));    // :367
-            bias = gclamp(gmax(baseBias, biasFromFootprint), baseBias, biasMax);  // :368
-            float radiusScale = gclamp(sqrt_(gmax(footprint, 1e-4f) / 0.03f), 1.0f, 1.6f);  // :371
-            radius = baseRadius * radiusScale;                                  // :372
-
-            origin = offsetRay(worldPos, geomNormal);                           // :375
-            buildTbn(geomNormal, &tT, &tB);                                     // :376
-            tMin = gmax(1e-4f, bias * 0.25f);                                   // :377
-
-            if (debugMode == 10u) histCurr[o] = float_to_half(gclamp(bias / 0.05f, 0.0f, 1.0f));            // :381-385
-            else if (debugMode == 11u) histCurr[o] = float_to_half(gclamp(footprint / 0.05f, 0.0f, 1.0f));  // :386-390
-            else valid = true;
-        }
-    }
-    s_radius[threadIdx.x] = radius;
+    PixelCtx pc;
+    pc.valid = false;
+    pc.radius = 0.0f;
+    if (px < W && py < y1) setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);   // :233-235
+    const bool valid = pc.valid;
+    s_radius[threadIdx.x] = pc.radius;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long vmask = __ballot(valid);
     const uint32_t nvalid = (uint32_t)__popcll(vmask);
     if (nvalid == 0) return;   // wave-uniform: nothing to trace, nothing to resolve
     if (valid) {
         const uint32_t rank = (uint32_t)__popcll(vmask & lt_mask);
-        float frameTerm = (rayCount >= 4) ? (fp.frameIndex * 131.0f) : 0.0f;    // :395
-        float seedBase = ((float)px * 1.0f + (float)py * 57.0f) + frameTerm;    // :396
-        float angle = hash11(seedBase) * 6.28318530718f;                        // :397
-        det_sincos(angle, &sn, &cs);                                            // :398-399
         for (int i = 0; i < rayCount; ++i) {                                    // :403-430
-            float xix = (float)i / gmax((float)rayCount, 1.0f);                 // hammersley :79-82
-            float xiy = radicalInverseVdC((uint32_t)i);
-            float ax = xix - 0.5f, ay = xiy - 0.5f;
-            float rx = (cs * ax + sn * ay) + 0.5f;                              // rot*(xi-0.5)+0.5, :400,405
-            float ry = (-sn * ax + cs * ay) + 0.5f;
-            rx = gclamp(rx, 0.0f, 1.0f);                                        // :406
-            ry = gclamp(ry, 0.0f, 1.0f);
-            float phi = 6.28318530718f * rx;                                    // :408
-            float cosTheta = sqrt_(1.0f - ry), sinTheta = sqrt_(ry);            // :409-410
-            float sphi, cphi;
-            det_sincos(phi, &sphi, &cphi);
-            V3 l = V3{cphi * sinTheta, sphi * sinTheta, cosTheta};              // :411
-            V3 rd = V3{(tT.x * l.x + tB.x * l.y) + geomNormal.x * l.z, (tT.y * l.x + tB.y * l.y) + geomNormal.y * l.z,
-                       (tT.z * l.x + tB.z * l.y) + geomNormal.z * l.z};
-            V3 rayDir = normalize3(rd);                                         // :412
-            float nd = gclamp(dot3(geomNormal, rayDir), 0.0f, 1.0f);            // :418
-            float grazing = 1.0f - nd;
-            float slopeScaled = gmax(bias * 0.5f, footprint * 0.02f);           // :421
-            float dirOffset = slopeScaled * (0.15f + (1.5f * grazing) * grazing);  // :422
-            V3 rayOrigin = origin + rayDir * dirOffset;                         // :423
-            float tMinRay = tMin;                                               // :427-429
-            tMinRay = gmax(tMinRay, dirOffset * 2.5f);
-            tMinRay = gmax(tMinRay, ((radius * 0.03f) * grazing) * grazing);
+            V3 rayOrigin, rayDir;
+            float tMinRay;
+            make_ray(pc, rayCount, i, &rayOrigin, &rayDir, &tMinRay);
             float4* rec = slice + ((size_t)i * nvalid + rank) * 2u;
             rec[0] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
             rec[1] = make_float4(rayDir.x, rayDir.y, rayDir.z, u2f((uint32_t)i * 64u + (uint32_t)lane));
@@ -299,30 +333,16 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
         const uint32_t total = nvalid * (uint32_t)rayCount;
         uint32_t next = 0;                 // wave-uniform
         bool active = false, found = false, retried = false;
-        int cur = CUR_DONE, sp = 0;
+        uint32_t spill[2 * (VKR_MAX_STACK - VKR_LDS_STACK)];   // scratch: touched only by rays deeper than the LDS part
+        int cur = CUR_DONE;
+        uint32_t sp = 0;
         V3 ro = v3(0, 0, 0), rdir = v3(0, 0, 1), id = v3(0, 0, 0);
         float tmin = 0.0f, tmin0 = 0.0f, tmax = 0.0f, tbest = 0.0f, adv = 0.0f;
         uint32_t rid = 0;
-        uint32_t spill[2 * (VKR_MAX_STACK - VKR_LDS_STACK)];
         TraceCounters cnt{0, 0, 0, 0};
         uint32_t nrays = 0;
-
-        auto pop = [&]() {
-            cur = CUR_DONE;
-            const float tb = tbest * 1.000001f;
-            while (sp > 0) {
-                --sp;
-                uint32_t key, ref;
-                if (sp < VKR_LDS_STACK) { key = stack[(2 * sp) * B]; ref = stack[(2 * sp + 1) * B]; }
-                else { key = spill[2 * (sp - VKR_LDS_STACK)]; ref = spill[2 * (sp - VKR_LDS_STACK) + 1]; }
-                if (u2f(key & ~3u) <= tb) { cur = (int)ref; break; }
-            }
-        };
-        auto push = [&](uint32_t key, uint32_t ref) {
-            if (sp < VKR_LDS_STACK) { stack[(2 * sp) * B] = key; stack[(2 * sp + 1) * B] = ref; }
-            else { spill[2 * (sp - VKR_LDS_STACK)] = key; spill[2 * (sp - VKR_LDS_STACK) + 1] = ref; }
-            ++sp;
-        };
+        const char* node_base = (const char*)sc.nodes;
+        const char* tri_base = (const char*)sc.tris;
 
         for (;;) {
             // ---- a ray whose traversal ended: self-hit retry (:193-200) or result (:187-189,205-212)
@@ -366,41 +386,66 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
             if (__ballot(active) == 0ull) break;
 
             // ---- one step per iteration, chosen per wave: lanes holding a node and lanes holding a leaf do not
-            // wait for each other's loops to drain; the cheaper triangle step runs as soon as a quarter as many
-            // lanes want it as want a node step.
+            // wait for each other's loops to drain; the cheaper triangle step runs as soon as 1/VKR_LEAF_VOTE as
+            // many lanes want it as want a node step.
             const int n_node = __popcll(__ballot(cur >= 0));
             const int n_leaf = __popcll(__ballot(cur < 0 && cur != CUR_DONE));
-            if (n_leaf == 0 || n_leaf * VKR_LEAF_VOTE < n_node) {
+            const float tb = tbest * 1.000001f;   // padded: culling may only err towards extra visits
+            bool need_pop = false;
+            if (n_leaf == 0 || n_leaf * VKR_LEAF_VOTE < n_node * VKR_LEAF_VOTE_DEN) {
                 if (cur >= 0) {
-                    const float4* np = sc.nodes + (size_t)cur * 8;
+                    const float4* np = (const float4*)(node_base + ((size_t)(uint32_t)cur << 7));
                     float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5], ch = np[6];
                     if (STATS) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.wave_node_iters++; }
-                    const float tb = tbest * 1.000001f;
-                    uint32_t k0 = box_key(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, ro, id, tmin, tb, 0u);
-                    uint32_t k1 = box_key(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, ro, id, tmin, tb, 1u);
-                    uint32_t k2 = box_key(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, ro, id, tmin, tb, 2u);
-                    uint32_t k3 = box_key(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, ro, id, tmin, tb, 3u);
-                    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);  // ascending
-                    auto ref_of = [&](uint32_t key) -> uint32_t {
-                        uint32_t s = key & 3u;
-                        float r = s == 0u ? ch.x : (s == 1u ? ch.y : (s == 2u ? ch.z : ch.w));
-                        return f2u(r);
-                    };
-                    if (k0 == 0xffffffffu) {
-                        pop();
+                    // slab tests; node boxes carry the conservative padding (bvh_build.hip tri_box), AO rays are short
+                    uint32_t k0, k1, k2, k3, r0 = f2u(ch.x), r1 = f2u(ch.y), r2 = f2u(ch.z), r3 = f2u(ch.w);
+#define VKR_SLAB(K, C)                                                                                              \
+    {                                                                                                               \
+        float ax0 = (mnx.C - ro.x) * id.x, ax1 = (mxx.C - ro.x) * id.x;                                            \
+        float ay0 = (mny.C - ro.y) * id.y, ay1 = (mxy.C - ro.y) * id.y;                                            \
+        float az0 = (mnz.C - ro.z) * id.z, az1 = (mxz.C - ro.z) * id.z;                                            \
+        float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),          \
+                                   __builtin_fmaxf(__builtin_fminf(az0, az1), tmin));                              \
+        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),          \
+                                   __builtin_fminf(__builtin_fmaxf(az0, az1), tb));                                \
+        K = (tn <= tf) ? f2u(tn) : 0xffffffffu;                                                                    \
+    }
+                    VKR_SLAB(k0, x) VKR_SLAB(k1, y) VKR_SLAB(k2, z) VKR_SLAB(k3, w)
+#undef VKR_SLAB
+                    // 5-exchange network on (tnear bits, child) pairs; tnear >= 0 orders as an unsigned integer
+#define VKR_CSWAP(KA, RA, KB, RB)                                                                                  \
+    {                                                                                                               \
+        bool sw = KB < KA;                                                                                          \
+        uint32_t tk = sw ? KB : KA, tr = sw ? RB : RA;                                                              \
+        KB = sw ? KA : KB; RB = sw ? RA : RB; KA = tk; RA = tr;                                                     \
+    }
+                    VKR_CSWAP(k0, r0, k1, r1) VKR_CSWAP(k2, r2, k3, r3) VKR_CSWAP(k0, r0, k2, r2)
+                    VKR_CSWAP(k1, r1, k3, r3) VKR_CSWAP(k1, r1, k2, r2)
+#undef VKR_CSWAP
+                    // deferred children, far first.  Common case: all three slots are still inside the LDS part of
+                    // the stack; only a lane that is about to run past it takes the scratch-aware path.
+                    if (sp + 3u <= (uint32_t)VKR_LDS_STACK) {
+                        if (k3 != 0xffffffffu) { stack[(2 * sp) * B] = k3; stack[(2 * sp + 1) * B] = r3; ++sp; }
+                        if (k2 != 0xffffffffu) { stack[(2 * sp) * B] = k2; stack[(2 * sp + 1) * B] = r2; ++sp; }
+                        if (k1 != 0xffffffffu) { stack[(2 * sp) * B] = k1; stack[(2 * sp + 1) * B] = r1; ++sp; }
                     } else {
-                        if (k3 != 0xffffffffu) push(k3, ref_of(k3));
-                        if (k2 != 0xffffffffu) push(k2, ref_of(k2));
-                        if (k1 != 0xffffffffu) push(k1, ref_of(k1));
-                        cur = (int)ref_of(k0);
+#define VKR_PUSH(K, R)                                                                                             \
+    if (K != 0xffffffffu) {                                                                                         \
+        if (sp < (uint32_t)VKR_LDS_STACK) { stack[(2 * sp) * B] = K; stack[(2 * sp + 1) * B] = R; }                 \
+        else { spill[2 * (sp - VKR_LDS_STACK)] = K; spill[2 * (sp - VKR_LDS_STACK) + 1] = R; }                      \
+        ++sp;                                                                                                       \
+    }
+                        VKR_PUSH(k3, r3) VKR_PUSH(k2, r2) VKR_PUSH(k1, r1)
+#undef VKR_PUSH
                     }
+                    if (k0 != 0xffffffffu) cur = (int)r0; else need_pop = true;
                 }
             } else if (cur < 0 && cur != CUR_DONE) {
                 // ---- leaf: ONE triangle per step (queryAoClosestHit :125-182, closest committed hit)
                 uint32_t x = (uint32_t)(~cur);
                 uint32_t first = x & 0x0fffffffu, rest = (x >> 28) & 7u;     // rest = triangles after this one
                 {
-                    const float4* tp = sc.tris + (size_t)first * 3;
+                    const float4* tp = (const float4*)(tri_base + (size_t)first * 48u);
                     float4 a = tp[0], b = tp[1], c = tp[2];
                     if (STATS) { cnt.tris++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.wave_tri_iters++; }
                     V3 v0 = V3{a.x, a.y, a.z}, e1 = V3{b.x, b.y, b.z}, e2 = V3{c.x, c.y, c.z};
@@ -412,18 +457,27 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
                     V3 qvec = cross3(tvec, e1);
                     float v = dot3(rdir, qvec) * inv;
                     float t = dot3(e2, qvec) * inv;
+                    const uint32_t mw = f2u(a.w);
+                    const uint32_t cls = mw >> 28;                              // candidate filter :142-173
                     bool hit = (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
-                               (t > tmin && t < tbest);
-                    if (hit) {
-                        uint32_t mw = f2u(a.w);
-                        uint32_t cls = mw >> 28;                                // candidate filter :142-173
-                        if (cls == 1u) hit = false;
-                        else if (cls == 2u) hit = alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), u, v);
-                    }
+                               (t > tmin && t < tbest) && (cls != 1u);
+                    if (hit && cls == 2u) hit = alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), u, v);
                     if (hit) { tbest = t; found = true; }
                 }
                 if (rest != 0u) cur = (int)(~((first + 1u) | ((rest - 1u) << 28)));
-                else pop();
+                else need_pop = true;
+            }
+            // ---- next entry still in front of the closest hit (entries carry their tnear)
+            if (need_pop) {
+                cur = CUR_DONE;
+                const float tb2 = tbest * 1.000001f;
+                while (sp > 0) {
+                    --sp;
+                    uint32_t key, ref;
+                    if (sp < (uint32_t)VKR_LDS_STACK) { key = stack[(2 * sp) * B]; ref = stack[(2 * sp + 1) * B]; }
+                    else { key = spill[2 * (sp - VKR_LDS_STACK)]; ref = spill[2 * (sp - VKR_LDS_STACK) + 1]; }
+                    if (u2f(key) <= tb2) { cur = (int)ref; break; }
+                }
             }
         }
         if (STATS) {
@@ -446,33 +500,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
         visibility += u2f(r & 0x7fffffffu);
         mask |= (r >> 31) << i;
     }
-    if (hitMask) hitMask[o] = mask;
-    float current = visibility / (float)rayCount;                               // :433
-    if (debugMode == 12u) { histCurr[o] = float_to_half(gclamp(current, 0.0f, 1.0f)); return; }  // :435-438
-
-    float hu = ((float)px + 0.5f) / (float)W, hv = ((float)py + 0.5f) / (float)H;  // :440
-    V2 prevUv = V2{hu, hv};
-    bool hasPrev = computePrevUv(fp.prevViewProj, worldPos, &prevUv);           // :442
-    float su = hasPrev ? prevUv.x : hu, sv = hasPrev ? prevUv.y : hv;
-    float history = tex_linear_r(histPrev, su, sv);                             // :443
-    float prevViewZ = tex_nearest_r(depth, su, sv);                             // :444
-    if (prevViewZ <= 1e-6f) prevViewZ = viewZ;                                  // :445-447
-    float depthDiff = __builtin_fabsf(prevViewZ - viewZ) / gmax(viewZ, 1e-3f);  // :449
-    float temporalAlpha = gclamp(fp.temporalAlphaRaw, 0.0f, 0.99f);             // :450
-    float baseThreshold = gmax(fp.disocclusionRaw, 0.0f);                       // :452
-    float noiseTerm = 0.6f / sqrt_((float)rayCount);                            // :453
-    float disocclusionThreshold = gclamp(baseThreshold + noiseTerm, 0.0f, 1.5f);  // :454
-    float variance = gmax(current * (1.0f - current), 0.0f) / (float)rayCount;  // :457
-    float sigma = sqrt_(variance);                                              // :458
-    float clampK = 2.5f;
-    float historyClamped = gclamp(history, current - clampK * sigma, current + clampK * sigma);  // :460
-    float delta = __builtin_fabsf(current - historyClamped);                    // :462
-    float rejectDelta = smoothstep_(disocclusionThreshold, disocclusionThreshold * 2.0f + 1e-5f, delta);  // :463
-    float rejectDepth = smoothstep_(0.02f, 0.15f, depthDiff);                   // :466
-    float reject = gmax(rejectDelta, rejectDepth);                              // :467
-    float historyWeight = (fp.frameIndex < 0.5f) ? 0.0f : (temporalAlpha * (1.0f - reject));  // :468
-    float accum = mixf(current, historyClamped, historyWeight);                 // :469
-    histCurr[o] = float_to_half(accum);                                         // :471
+    resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc, visibility, mask);
 }
 
 hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,
@@ -481,21 +509,21 @@ hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* 
     if (y1 <= y0) return hipSuccess;
     uint32_t tiles_x = ((uint32_t)fp.W + 7u) / 8u, tiles_y = ((uint32_t)(y1 - y0) + 7u) / 8u;
     uint32_t n_tiles = tiles_x * tiles_y;
-    // ray buffer: one slice per wave of the launch, sized for the current rays/px (grow-only)
+    // ray buffer: one slice per wave of the launch, sized for the current rays/px (grow-only, so steady-state
+    // frames allocate nothing)
     size_t need = (size_t)n_tiles * ((size_t)fp.rayCount * 64u * 2u + (size_t)fp.rayCount * 16u);
     if (c->d_raybuf.n < need) {
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
-        e = c->d_raybuf.alloc(need);
-        if (e != hipSuccess) return e;
+        if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
     }
     SceneDev sc = scene_dev(c);
     if (c->stats_enabled)
-        k_trace<true><<<n_tiles, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1,
-                                                          tiles_x, n_tiles, c->d_raybuf.p, c->d_stats.p);
+        k_trace<true><<<n_tiles, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
+                                                   c->d_raybuf.p, c->d_stats.p);
     else
-        k_trace<false><<<n_tiles, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1,
-                                                           tiles_x, n_tiles, c->d_raybuf.p, nullptr);
+        k_trace<false><<<n_tiles, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
+                                                    c->d_raybuf.p, nullptr);
     return hipGetLastError();
 }
 

@@ -25,7 +25,10 @@ constexpr int VKR_TRACE_BLOCK = 256;
 constexpr int VKR_LEAF_MAX = 4;      // triangles per leaf (encoding allows 8)
 constexpr uint32_t VKR_CHILD_NONE = 0x7fffffffu;
 #ifndef VKR_LEAF_VOTE
-#define VKR_LEAF_VOTE 4   // K1 runs a triangle step when n_leaf * VKR_LEAF_VOTE >= n_node
+#define VKR_LEAF_VOTE 1   // K1 runs a triangle step when n_leaf * VKR_LEAF_VOTE >= n_node * VKR_LEAF_VOTE_DEN
+#endif
+#ifndef VKR_LEAF_VOTE_DEN
+#define VKR_LEAF_VOTE_DEN 1
 #endif
 
 struct AlphaTexDev { uint32_t offset, w, h, pad; };
@@ -115,7 +118,7 @@ VKR_DI void cswap(uint32_t& a, uint32_t& b)
 // MODE Q_SHADOW  : any hit, every triangle occludes (gl_RayFlagsOpaqueEXT|TerminateOnFirstHit, pbr.frag:199-215)
 // MODE Q_PRIMARY : as Q_AO, ties in t resolved towards the lower flat triangle id (G-buffer producer)
 // `stack` points at this lane's column of the block's LDS stack: entry k = {stack[(2k)*B], stack[(2k+1)*B]}.
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, int B = VKR_TRACE_BLOCK>
 __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, HitDev* hit,
                                          uint32_t* stack, TraceCounters* cnt)
 {
@@ -129,8 +132,6 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
     uint2 spill[VKR_MAX_STACK - VKR_LDS_STACK];
     int sp = 0;
     int cur = 0;  // root
-    constexpr int B = VKR_TRACE_BLOCK;
-
     auto push = [&](uint32_t key, uint32_t ref) {
         if (sp < VKR_LDS_STACK) { stack[(2 * sp) * B] = key; stack[(2 * sp + 1) * B] = ref; }
         else spill[sp - VKR_LDS_STACK] = make_uint2(key, ref);

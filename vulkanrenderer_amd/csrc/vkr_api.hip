@@ -568,8 +568,9 @@ int vkr_trace_stats_get(vkr_ctx* c, vkr_trace_stats* out, int reset)
     if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
     if (int rc = set_device(c)) return rc;
     HIP_OR_FAIL(c, hipDeviceSynchronize());
-    unsigned long long h[5];
-    HIP_OR_FAIL(c, hipMemcpy(h, c->d_stats.p, 40, hipMemcpyDeviceToHost));
+    unsigned long long h[6];
+    HIP_OR_FAIL(c, hipMemcpy(h, c->d_stats.p, 48, hipMemcpyDeviceToHost));
+    out->overflow_tiles = h[5];
     out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
     out->wave_node_iters = h[3]; out->wave_tri_iters = h[4];
     if (reset) HIP_OR_FAIL(c, hipMemset(c->d_stats.p, 0, 64));
