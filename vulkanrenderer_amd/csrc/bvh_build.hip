@@ -338,7 +338,15 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint64_t* keys, int n, 
 }
 
 // padded AABB of sorted triangle j (padding keeps the slab test conservative w.r.t. the triangle test)
-VKR_DI void tri_box(const float4* tris, uint32_t j, float lo[3], float hi[3])
+VKR_DI float pad_abs_of(const BvhBounds* bnd)
+{
+    float e = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e += dec_f(bnd->tri_max[k]) - dec_f(bnd->tri_min[k]);
+    return 4.0e-7f * e + 1.0e-6f;   // covers the rounding of the folded slab form at every level of the tree
+}
+
+VKR_DI void tri_box(const float4* tris, uint32_t j, float pad_abs, float lo[3], float hi[3])
 {
     const float4* tp = tris + (size_t)j * 3;
     float4 a = tp[0], b = tp[1], c = tp[2];
@@ -349,7 +357,7 @@ VKR_DI void tri_box(const float4* tris, uint32_t j, float lo[3], float hi[3])
     for (int k = 0; k < 3; ++k) {
         float l = __builtin_fminf(v0[k], __builtin_fminf(v1[k], v2[k]));
         float h = __builtin_fmaxf(v0[k], __builtin_fmaxf(v1[k], v2[k]));
-        float pad = 1e-5f * __builtin_fmaxf(__builtin_fabsf(l), __builtin_fabsf(h)) + 1e-6f;
+        float pad = 1e-5f * __builtin_fmaxf(__builtin_fabsf(l), __builtin_fabsf(h)) + pad_abs;
         lo[k] = l - pad;
         hi[k] = h + pad;
     }
@@ -371,12 +379,13 @@ VKR_DI u64 pack2(float a, float b) { return (u64)f2u(a) | ((u64)f2u(b) << 32); }
 
 __global__ __launch_bounds__(256) void k_fit(const float4* tris, int n, const int2* bin_child, u64* deposit,
                                              float4* node_box, const uint32_t* leaf_parent,
-                                             const uint32_t* node_parent, uint32_t* flags, uint32_t* height_out)
+                                             const uint32_t* node_parent, uint32_t* flags, uint32_t* height_out,
+                                             const BvhBounds* bnd)
 {
     int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     float lo[3], hi[3];
-    tri_box(tris, (uint32_t)j, lo, hi);
+    tri_box(tris, (uint32_t)j, pad_abs_of(bnd), lo, hi);
     int child = ~j;
     uint32_t p = leaf_parent[j];
     uint32_t h = 0;  // height of the subtree rooted at `child`, in internal nodes
@@ -427,37 +436,75 @@ VKR_DI float half_area(const float4& mn, const float4& mx)
     return dx * dy + dy * dz + dz * dx;
 }
 
-VKR_DI void cand_box(int c, const float4* node_box, const float4* tris, float lo[3], float hi[3])
+VKR_DI void cand_box(int c, const float4* node_box, const float4* tris, float pad_abs, float lo[3], float hi[3])
 {
     if (c >= 0) {
         float4 mn = node_box[(size_t)c * 2], mx = node_box[(size_t)c * 2 + 1];
         lo[0] = mn.x; lo[1] = mn.y; lo[2] = mn.z; hi[0] = mx.x; hi[1] = mx.y; hi[2] = mx.z;
     } else {
-        tri_box(tris, (uint32_t)(~c), lo, hi);
+        tri_box(tris, (uint32_t)(~c), pad_abs, lo, hi);
     }
 }
 
-// writes boxes (q0..q5) of wide node w from its children's binary refs (q7)
-VKR_DI void write_wide_boxes(float4* node, const int cand[4], int ncand, const float4* node_box, const float4* tris)
+// Writes q0..q2 of wide node `node` (traverse.hpp layout): the children's boxes quantised to 8 bits per plane in
+// the frame of their union.  origin = union min; per axis scale = 2^e with 254 * scale >= extent; child plane =
+// fma(q, scale, origin), the SAME expression the traversal evaluates, so the rounding checks below make the
+// decoded box contain the exact one.
+VKR_DI void write_wide_boxes(float4* node, const int cand[4], int ncand, const float4* node_box, const float4* tris,
+                             float pad_abs)
 {
-    float mn[3][4], mx[3][4];
+    float lo[4][3], hi[4][3];
+    float ulo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, uhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {3.0e38f, 3.0e38f, 3.0e38f};
-        if (k < ncand) cand_box(cand[k], node_box, tris, lo, hi);
+        if (k < ncand) {
+            cand_box(cand[k], node_box, tris, pad_abs, lo[k], hi[k]);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { mn[a][k] = lo[a]; mx[a][k] = hi[a]; }
+            for (int a = 0; a < 3; ++a) { ulo[a] = __builtin_fminf(ulo[a], lo[k][a]); uhi[a] = __builtin_fmaxf(uhi[a], hi[k][a]); }
+        }
     }
+    float scale[3];
+    uint32_t ebits = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        node[a] = make_float4(mn[a][0], mn[a][1], mn[a][2], mn[a][3]);
-        node[3 + a] = make_float4(mx[a][0], mx[a][1], mx[a][2], mx[a][3]);
+        float ext = (uhi[a] - ulo[a]) * (1.0f / 254.0f);
+        // smallest power of two >= ext (>= 2^-100 so the exponent byte is never 0 and 1/scale stays finite)
+        uint32_t e = (f2u(ext) >> 23) & 0xffu;
+        if ((f2u(ext) & 0x7fffffu) != 0u) e += 1u;
+        if (e < 27u) e = 27u;
+        if (e > 254u) e = 254u;
+        scale[a] = u2f(e << 23);
+        ebits |= e << (8 * a);
     }
+    uint32_t q[6] = {0, 0, 0, 0, 0, 0};   // qminx, qminy, qminz, qmaxx, qmaxy, qmaxz : one byte per child
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            uint32_t ql = 255u, qh = 0u;   // unused slot: inverted, misses every slab test
+            if (k < ncand) {
+                float inv = 1.0f / scale[a];
+                float fl = __builtin_floorf((lo[k][a] - ulo[a]) * inv);
+                float fh = __builtin_ceilf((hi[k][a] - ulo[a]) * inv);
+                int il = fl < 0.0f ? 0 : (fl > 255.0f ? 255 : (int)fl);
+                int ih = fh < 0.0f ? 0 : (fh > 255.0f ? 255 : (int)fh);
+                while (il > 0 && fma_((float)il, scale[a], ulo[a]) > lo[k][a]) --il;
+                while (ih < 255 && fma_((float)ih, scale[a], ulo[a]) < hi[k][a]) ++ih;
+                ql = (uint32_t)il;
+                qh = (uint32_t)ih;
+            }
+            q[a] |= ql << (8 * k);
+            q[3 + a] |= qh << (8 * k);
+        }
+    }
+    node[0] = make_float4(ulo[0], ulo[1], ulo[2], u2f(ebits | ((uint32_t)ncand << 24)));
+    node[1] = make_float4(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3]));
+    node[2] = make_float4(u2f(q[4]), u2f(q[5]), 0.0f, 0.0f);
 }
 
 __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bin_child, const uint2* bin_range,
                                                     const float4* node_box, const float4* tris, float4* nodes,
-                                                    uint32_t* wide_bin)
+                                                    uint4* wide_bref, uint32_t* wide_bin, const BvhBounds* bnd)
 {
     const uint32_t begin = ctl->level_begin, end = ctl->level_end;
     uint32_t w = begin + blockIdx.x * 256u + threadIdx.x;
@@ -489,8 +536,8 @@ __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bi
         cand[pick] = c.x;
         cand[ncand++] = c.y;
     }
-    float4* node = nodes + (size_t)w * 8;
-    write_wide_boxes(node, cand, ncand, node_box, tris);
+    float4* node = nodes + (size_t)w * 4;
+    write_wide_boxes(node, cand, ncand, node_box, tris, pad_abs_of(bnd));
     uint32_t ref[4], bref[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -510,8 +557,8 @@ __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bi
             }
         }
     }
-    node[6] = make_float4(u2f(ref[0]), u2f(ref[1]), u2f(ref[2]), u2f(ref[3]));
-    node[7] = make_float4(u2f(bref[0]), u2f(bref[1]), u2f(bref[2]), u2f(bref[3]));
+    node[3] = make_float4(u2f(ref[0]), u2f(ref[1]), u2f(ref[2]), u2f(ref[3]));
+    wide_bref[w] = make_uint4(bref[0], bref[1], bref[2], bref[3]);
 }
 
 __global__ void k_wide_init(WideCtl* ctl, uint32_t* wide_bin)
@@ -533,27 +580,29 @@ __global__ void k_wide_next(WideCtl* ctl)
 
 // refit: same topology, new boxes
 __global__ __launch_bounds__(256) void k_wide_refit(uint32_t count, const float4* node_box, const float4* tris,
-                                                    float4* nodes)
+                                                    float4* nodes, const uint4* wide_bref, const BvhBounds* bnd)
 {
     uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= count) return;
-    float4* node = nodes + (size_t)w * 8;
-    float4 br = node[7];
-    int cand[4] = {(int)f2u(br.x), (int)f2u(br.y), (int)f2u(br.z), (int)f2u(br.w)};
+    uint4 br = wide_bref[w];
+    int cand[4] = {(int)br.x, (int)br.y, (int)br.z, (int)br.w};
     int ncand = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (f2u(k == 0 ? br.x : k == 1 ? br.y : k == 2 ? br.z : br.w) != VKR_CHILD_NONE) ncand = k + 1;
-    write_wide_boxes(node, cand, ncand, node_box, tris);
+    if (br.x != VKR_CHILD_NONE) ncand = 1;
+    if (br.y != VKR_CHILD_NONE) ncand = 2;
+    if (br.z != VKR_CHILD_NONE) ncand = 3;
+    if (br.w != VKR_CHILD_NONE) ncand = 4;
+    write_wide_boxes(nodes + (size_t)w * 4, cand, ncand, node_box, tris, pad_abs_of(bnd));
 }
 
 // n == 1: a root with one single-triangle leaf
-__global__ void k_single(const float4* tris, float4* nodes, uint32_t* height_out, WideCtl* ctl)
+__global__ void k_single(const float4* tris, float4* nodes, uint4* wide_bref, uint32_t* height_out, WideCtl* ctl,
+                         const BvhBounds* bnd)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int cand[4] = {~0, 0, 0, 0};
-    write_wide_boxes(nodes, cand, 1, nullptr, tris);
-    nodes[6] = make_float4(u2f(~0u), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE));
-    nodes[7] = nodes[6];
+    write_wide_boxes(nodes, cand, 1, nullptr, tris, pad_abs_of(bnd));
+    nodes[3] = make_float4(u2f(~0u), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE));
+    wide_bref[0] = make_uint4(~0u, VKR_CHILD_NONE, VKR_CHILD_NONE, VKR_CHILD_NONE);
     *height_out = 1u;
     ctl->count = 1; ctl->levels = 1; ctl->level_begin = 1; ctl->level_end = 1;
 }
@@ -572,9 +621,9 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     in.inst_xf = c->d_inst_xf.p; in.instance_count = c->instance_count; in.tri_count = n;
     const uint32_t nb = (n + 255u) / 256u;
 
+    k_bounds_init<<<1, 64, 0, st>>>(c->d_bounds.p);   // also on refit: transforms move the scene, and the
+    k_bounds<<<nb, 256, 0, st>>>(in, c->d_bounds.p);   // conservative padding scales with its extent
     if (!refit_only) {
-        k_bounds_init<<<1, 64, 0, st>>>(c->d_bounds.p);
-        k_bounds<<<nb, 256, 0, st>>>(in, c->d_bounds.p);
         k_morton<<<nb, 256, 0, st>>>(in, c->d_bounds.p, c->morton_bits, c->d_keys[0].p, c->d_vals[0].p);
         const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
         const int key_bits = 3 * (int)c->morton_bits;
@@ -594,15 +643,16 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     }
     k_emit_sorted<<<nb, 256, 0, st>>>(in, c->d_perm.p, c->d_tris.p);
     if (n == 1) {
-        k_single<<<1, 64, 0, st>>>(c->d_tris.p, c->d_nodes.p, c->d_height.p, (WideCtl*)c->d_wide_ctl.p);
+        k_single<<<1, 64, 0, st>>>(c->d_tris.p, c->d_nodes.p, c->d_wide_bref.p, c->d_height.p, (WideCtl*)c->d_wide_ctl.p,
+                                   c->d_bounds.p);
         return hipGetLastError();
     }
     VKR_TRY(hipMemsetAsync(c->d_flags.p, 0, (size_t)(n - 1) * 4, st));
     k_fit<<<nb, 256, 0, st>>>(c->d_tris.p, (int)n, c->d_bin_child.p, (u64*)c->d_deposit.p, c->d_node_box.p,
-                              c->d_leaf_parent.p, c->d_node_parent.p, c->d_flags.p, c->d_height.p);
+                              c->d_leaf_parent.p, c->d_node_parent.p, c->d_flags.p, c->d_height.p, c->d_bounds.p);
     if (refit_only) {
         k_wide_refit<<<(c->wide_count + 255u) / 256u, 256, 0, st>>>(c->wide_count, c->d_node_box.p, c->d_tris.p,
-                                                                    c->d_nodes.p);
+                                                                    c->d_nodes.p, c->d_wide_bref.p, c->d_bounds.p);
     }
     return hipGetLastError();
 }
@@ -619,7 +669,7 @@ hipError_t bvh_wide_launch(vkr_ctx* c, uint32_t bin_height, hipStream_t st)
         uint64_t width = cap < (uint64_t)n ? cap : (uint64_t)n;   // a level never holds more than 4^level nodes
         k_wide_level<<<(uint32_t)((width + 255u) / 256u), 256, 0, st>>>(ctl, c->d_bin_child.p, c->d_bin_range.p,
                                                                         c->d_node_box.p, c->d_tris.p, c->d_nodes.p,
-                                                                        c->d_wide_bin.p);
+                                                                        c->d_wide_bref.p, c->d_wide_bin.p, c->d_bounds.p);
         k_wide_next<<<1, 64, 0, st>>>(ctl);
         if (cap < (uint64_t)n) cap *= 4;
     }

@@ -101,6 +101,15 @@ VKR_DI bool computePrevUv(const float* prevViewProj, V3 worldPos, V2* prevUv)  /
 // lane about to run past the LDS part, so it stays out of the common instruction stream.
 // ---------------------------------------------------------------------------------------------
 constexpr int CUR_DONE = (int)0x80000000;
+
+// 1/x for slab tests: approximate reciprocal, magnitude capped so that 0 * inf never appears (a ray parallel to a
+// slab then sees +-1e18-scaled distances, which order exactly like the infinite ones)
+VKR_DI float safe_rcp(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    float a = __builtin_fminf(__builtin_fabsf(r), 1.0e18f);
+    return __builtin_copysignf(a, x);
+}
 constexpr int K1_BLOCK = 64;
 
 VKR_DI uint32_t ray_slice_float4s(int rayCount) { return (uint32_t)rayCount * 64u * 2u + (uint32_t)rayCount * 16u; }
@@ -345,43 +354,50 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
         const char* tri_base = (const char*)sc.tris;
 
         for (;;) {
-            // ---- a ray whose traversal ended: self-hit retry (:193-200) or result (:187-189,205-212)
-            if (active && cur == CUR_DONE) {
-                if (found && !retried && tbest <= tmin0 * 1.5f) {
-                    adv = gmax(tmin0 * 2.0f, 2e-4f);
-                    ro = ro + rdir * adv;
-                    tmin = gmax(tmin0, 1e-4f);
-                    tbest = tmax; found = false; retried = true; cur = 0; sp = 0;
-                    if (STATS) nrays++;
-                } else {
-                    float vis = 1.0f;
-                    if (found) {
-                        float t = retried ? (tbest + adv) : tbest;
-                        if (!(t <= tmin0 * 1.5f)) {
-                            float x = gclamp((t - tmin0) / gmax(tmax - tmin0, 1e-3f), 0.0f, 1.0f);
-                            vis = u2f(f2u(pow3(x)) | 0x80000000u);   // sign bit: this ray ended occluded
+            // ---- service finished rays and pull new ones, in batches: doing this the moment any single lane
+            // finishes would run ~100 instructions at 1/64 utilisation per ray.
+            const unsigned long long donem = __ballot(active && cur == CUR_DONE);
+            const unsigned long long idlem = __ballot(!active);
+            const int n_serv = __popcll(donem) + ((next < total) ? __popcll(idlem) : 0);
+            if ((donem | idlem) == ~0ull || n_serv >= VKR_REFILL_BATCH) {
+                // a ray whose traversal ended: self-hit retry (:193-200) or result (:187-189,205-212)
+                if (active && cur == CUR_DONE) {
+                    if (found && !retried && tbest <= tmin0 * 1.5f) {
+                        adv = gmax(tmin0 * 2.0f, 2e-4f);
+                        ro = ro + rdir * adv;
+                        tmin = gmax(tmin0, 1e-4f);
+                        tbest = tmax; found = false; retried = true; cur = 0; sp = 0;
+                        if (STATS) nrays++;
+                    } else {
+                        float vis = 1.0f;
+                        if (found) {
+                            float t = retried ? (tbest + adv) : tbest;
+                            if (!(t <= tmin0 * 1.5f)) {
+                                float x = gclamp((t - tmin0) / gmax(tmax - tmin0, 1e-3f), 0.0f, 1.0f);
+                                vis = u2f(f2u(pow3(x)) | 0x80000000u);   // sign bit: this ray ended occluded
+                            }
+                        }
+                        results[rid] = vis;
+                        active = false;
+                    }
+                }
+                // idle lanes pull the next rays of the tile
+                const unsigned long long idle = __ballot(!active);
+                if (idle != 0ull && next < total) {
+                    if (!active) {
+                        uint32_t k = next + (uint32_t)__popcll(idle & lt_mask);
+                        if (k < total) {
+                            float4 a = slice[(size_t)k * 2u], b = slice[(size_t)k * 2u + 1u];
+                            ro = V3{a.x, a.y, a.z}; tmin = a.w; tmin0 = a.w;
+                            rdir = V3{b.x, b.y, b.z}; rid = f2u(b.w);
+                            id = V3{safe_rcp(rdir.x), safe_rcp(rdir.y), safe_rcp(rdir.z)};
+                            tmax = s_radius[rid & 63u];
+                            tbest = tmax; found = false; retried = false; cur = 0; sp = 0; active = true;
+                            if (STATS) nrays++;
                         }
                     }
-                    results[rid] = vis;
-                    active = false;
+                    next += (uint32_t)__popcll(idle);
                 }
-            }
-            // ---- idle lanes pull the next rays of the tile
-            const unsigned long long idle = __ballot(!active);
-            if (idle != 0ull && next < total) {
-                if (!active) {
-                    uint32_t k = next + (uint32_t)__popcll(idle & lt_mask);
-                    if (k < total) {
-                        float4 a = slice[(size_t)k * 2u], b = slice[(size_t)k * 2u + 1u];
-                        ro = V3{a.x, a.y, a.z}; tmin = a.w; tmin0 = a.w;
-                        rdir = V3{b.x, b.y, b.z}; rid = f2u(b.w);
-                        id = V3{__builtin_amdgcn_rcpf(rdir.x), __builtin_amdgcn_rcpf(rdir.y), __builtin_amdgcn_rcpf(rdir.z)};
-                        tmax = s_radius[rid & 63u];
-                        tbest = tmax; found = false; retried = false; cur = 0; sp = 0; active = true;
-                        if (STATS) nrays++;
-                    }
-                }
-                next += (uint32_t)__popcll(idle);
             }
             if (__ballot(active) == 0ull) break;
 
@@ -394,23 +410,31 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
             bool need_pop = false;
             if (n_leaf == 0 || n_leaf * VKR_LEAF_VOTE < n_node * VKR_LEAF_VOTE_DEN) {
                 if (cur >= 0) {
-                    const float4* np = (const float4*)(node_base + ((size_t)(uint32_t)cur << 7));
-                    float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5], ch = np[6];
+                    const float4* np = (const float4*)(node_base + ((size_t)(uint32_t)cur << 6));
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     if (STATS) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.wave_node_iters++; }
-                    // slab tests; node boxes carry the conservative padding (bvh_build.hip tri_box), AO rays are short
-                    uint32_t k0, k1, k2, k3, r0 = f2u(ch.x), r1 = f2u(ch.y), r2 = f2u(ch.z), r3 = f2u(ch.w);
+                    // Slab tests straight on the quantised planes: plane = fma(q, s, o), t = (plane - ro) * id
+                    // is evaluated as fma(q, s*id, (o - ro)*id): one fma per plane.  The direction sign picks the
+                    // near/far byte-quads once per axis, so no per-plane min/max; unused slots are stored inverted
+                    // (qmin = 255, qmax = 0) and miss by themselves.  Rounding of this form is covered by the leaf
+                    // padding (bvh_build.hip tri_box) and by the outward quantisation.
+                    const uint32_t eb = f2u(q0.w);
+                    const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
+                                az = u2f(((eb >> 16) & 0xffu) << 23) * id.z;
+                    const float bx = (q0.x - ro.x) * id.x, by = (q0.y - ro.y) * id.y, bz = (q0.z - ro.z) * id.z;
+                    const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
+                    const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
+                    const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
+                    uint32_t k0, k1, k2, k3, r0 = f2u(q3.x), r1 = f2u(q3.y), r2 = f2u(q3.z), r3 = f2u(q3.w);
 #define VKR_SLAB(K, C)                                                                                              \
     {                                                                                                               \
-        float ax0 = (mnx.C - ro.x) * id.x, ax1 = (mxx.C - ro.x) * id.x;                                            \
-        float ay0 = (mny.C - ro.y) * id.y, ay1 = (mxy.C - ro.y) * id.y;                                            \
-        float az0 = (mnz.C - ro.z) * id.z, az1 = (mxz.C - ro.z) * id.z;                                            \
-        float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),          \
-                                   __builtin_fmaxf(__builtin_fminf(az0, az1), tmin));                              \
-        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),          \
-                                   __builtin_fminf(__builtin_fmaxf(az0, az1), tb));                                \
+        float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(ubyte_f(nx4, C), ax, bx), fma_(ubyte_f(ny4, C), ay, by)),   \
+                                   __builtin_fmaxf(fma_(ubyte_f(nz4, C), az, bz), tmin));                          \
+        float tf = __builtin_fminf(__builtin_fminf(fma_(ubyte_f(fx4, C), ax, bx), fma_(ubyte_f(fy4, C), ay, by)),   \
+                                   __builtin_fminf(fma_(ubyte_f(fz4, C), az, bz), tb));                            \
         K = (tn <= tf) ? f2u(tn) : 0xffffffffu;                                                                    \
     }
-                    VKR_SLAB(k0, x) VKR_SLAB(k1, y) VKR_SLAB(k2, z) VKR_SLAB(k3, w)
+                    VKR_SLAB(k0, 0) VKR_SLAB(k1, 1) VKR_SLAB(k2, 2) VKR_SLAB(k3, 3)
 #undef VKR_SLAB
                     // 5-exchange network on (tnear bits, child) pairs; tnear >= 0 orders as an unsigned integer
 #define VKR_CSWAP(KA, RA, KB, RB)                                                                                  \

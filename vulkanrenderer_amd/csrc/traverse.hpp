@@ -1,11 +1,15 @@
 // traverse.hpp -- ray queries over the wide LBVH (replaces rayQueryEXT + the driver's TLAS/BLAS walk).
 //
 // Data layout in HBM (16-byte aligned, read as dwordx4 quarters):
-//   wide node (128 B = one cache line, up to 4 children, SoA so one quarter feeds four slab tests):
-//       q0 minx[4] | q1 miny[4] | q2 minz[4] | q3 maxx[4] | q4 maxy[4] | q5 maxz[4] | q6 child[4] | q7 build refs
+//   wide node (64 B, up to 4 children, boxes quantised to 8 bits per plane in the frame of their union --
+//   traversal is bound by L1/TA bytes per visit, not by arithmetic, so 64 B beats 128 B of float planes):
+//       q0 origin.xyz | ex | ey<<8 | ez<<16 | nchild<<24        (scale_a = 2^(e_a-127) = bits e_a<<23)
+//       q1 qminx[4] qminy[4] qminz[4] qmaxx[4]   (one byte per child, plane = fma(q, scale, origin))
+//       q2 qmaxy[4] qmaxz[4] 0 0
+//       q3 child[4]
 //       child >= 0            : wide node index
 //       child <  0            : leaf, x = ~child: first triangle = x & 0x0fffffff, count = ((x >> 28) & 7) + 1
-//       unused slot           : box min = max = 3e38 (never hit), child = 0x7fffffff
+//       unused slot           : child = 0x7fffffff (slots >= nchild are skipped)
 //   tri (48 B, Morton order so a leaf's triangles are contiguous):
 //       q0 = v0.xyz (mesh | class<<28) | q1 = e1.xyz prim | q2 = e2.xyz flat_id
 //       class: 0 = always an occluder for AO, 1 = never (BLEND), 2 = alpha-test (MASK)
@@ -26,6 +30,9 @@ constexpr int VKR_LEAF_MAX = 4;      // triangles per leaf (encoding allows 8)
 constexpr uint32_t VKR_CHILD_NONE = 0x7fffffffu;
 #ifndef VKR_LEAF_VOTE
 #define VKR_LEAF_VOTE 1   // K1 runs a triangle step when n_leaf * VKR_LEAF_VOTE >= n_node * VKR_LEAF_VOTE_DEN
+#endif
+#ifndef VKR_REFILL_BATCH
+#define VKR_REFILL_BATCH 8   // K1 services finished/idle lanes once this many have piled up (or none has work)
 #endif
 #ifndef VKR_LEAF_VOTE_DEN
 #define VKR_LEAF_VOTE_DEN 1
@@ -88,6 +95,32 @@ VKR_DI bool alpha_test(const SceneDev& sc, uint32_t mesh, uint32_t prim, float b
     float2 a = sc.uvs[i0], b = sc.uvs[i1], c = sc.uvs[i2];
     V2 uv = V2{(a.x * w0 + b.x * bu) + c.x * bv, (a.y * w0 + b.y * bu) + c.y * bv};
     return sample_alpha(sc, lut.x, uv) >= cutoff;
+}
+
+// One decoded wide node: 24 planes + 4 child refs.
+struct NodeDec {
+    float mnx[4], mny[4], mnz[4], mxx[4], mxy[4], mxz[4];
+    uint32_t ref[4];
+    uint32_t nchild;
+};
+
+VKR_DI float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
+
+VKR_DI void decode_node(const float4* np, NodeDec& n)
+{
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    const uint32_t eb = f2u(q0.w);
+    const float sx = u2f((eb & 0xffu) << 23), sy = u2f(((eb >> 8) & 0xffu) << 23), sz = u2f(((eb >> 16) & 0xffu) << 23);
+    n.nchild = eb >> 24;
+    const uint32_t wminx = f2u(q1.x), wminy = f2u(q1.y), wminz = f2u(q1.z), wmaxx = f2u(q1.w), wmaxy = f2u(q2.x),
+                   wmaxz = f2u(q2.y);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        n.mnx[k] = fma_(ubyte_f(wminx, k), sx, q0.x); n.mxx[k] = fma_(ubyte_f(wmaxx, k), sx, q0.x);
+        n.mny[k] = fma_(ubyte_f(wminy, k), sy, q0.y); n.mxy[k] = fma_(ubyte_f(wmaxy, k), sy, q0.y);
+        n.mnz[k] = fma_(ubyte_f(wminz, k), sz, q0.z); n.mxz[k] = fma_(ubyte_f(wmaxz, k), sz, q0.z);
+    }
+    n.ref[0] = f2u(q3.x); n.ref[1] = f2u(q3.y); n.ref[2] = f2u(q3.z); n.ref[3] = f2u(q3.w);
 }
 
 // Slab test of one child box against [tmin, tbest]; returns the packed sort key: tnear bits with the child
@@ -153,19 +186,21 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
     while (alive) {
         // ---- internal nodes: descend until this lane holds a leaf (or runs out of work)
         while (cur >= 0) {
-            const float4* np = sc.nodes + (size_t)cur * 8;
-            float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5], ch = np[6];
+            NodeDec nd;
+            decode_node(sc.nodes + (size_t)cur * 4, nd);
             if (STATS) { cnt->nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt->wave_node_iters++; }
             const float tb = tbest * 1.000001f;
-            uint32_t k0 = box_key(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, o, id, tmin, tb, 0u);
-            uint32_t k1 = box_key(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, o, id, tmin, tb, 1u);
-            uint32_t k2 = box_key(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, o, id, tmin, tb, 2u);
-            uint32_t k3 = box_key(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, o, id, tmin, tb, 3u);
+            uint32_t k0 = box_key(nd.mnx[0], nd.mny[0], nd.mnz[0], nd.mxx[0], nd.mxy[0], nd.mxz[0], o, id, tmin, tb, 0u);
+            uint32_t k1 = box_key(nd.mnx[1], nd.mny[1], nd.mnz[1], nd.mxx[1], nd.mxy[1], nd.mxz[1], o, id, tmin, tb, 1u);
+            uint32_t k2 = box_key(nd.mnx[2], nd.mny[2], nd.mnz[2], nd.mxx[2], nd.mxy[2], nd.mxz[2], o, id, tmin, tb, 2u);
+            uint32_t k3 = box_key(nd.mnx[3], nd.mny[3], nd.mnz[3], nd.mxx[3], nd.mxy[3], nd.mxz[3], o, id, tmin, tb, 3u);
+            if (nd.nchild < 2u) k1 = 0xffffffffu;
+            if (nd.nchild < 3u) k2 = 0xffffffffu;
+            if (nd.nchild < 4u) k3 = 0xffffffffu;
             cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);  // ascending
             auto ref_of = [&](uint32_t key) -> uint32_t {
                 uint32_t s = key & 3u;
-                float r = s == 0u ? ch.x : (s == 1u ? ch.y : (s == 2u ? ch.z : ch.w));
-                return f2u(r);
+                return s == 0u ? nd.ref[0] : (s == 1u ? nd.ref[1] : (s == 2u ? nd.ref[2] : nd.ref[3]));
             };
             if (k0 == 0xffffffffu) {           // nothing hit
                 if (!pop()) { alive = false; break; }

@@ -145,7 +145,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_nodes.release(); c->d_tris.release(); c->d_perm.release(); c->d_leaf_parent.release();
     c->d_node_parent.release(); c->d_flags.release();
     c->d_bin_child.release(); c->d_bin_range.release(); c->d_deposit.release(); c->d_node_box.release();
-    c->d_wide_ctl.release(); c->d_wide_bin.release();
+    c->d_wide_ctl.release(); c->d_wide_bin.release(); c->d_wide_bref.release();
     for (int i = 0; i < 2; ++i) { c->d_keys[i].release(); c->d_vals[i].release(); c->d_hist_img[i].release(); c->d_ping[i].release(); }
     c->d_hist.release(); c->d_digit_totals.release(); c->d_bounds.release(); c->d_height.release();
     c->d_nz.release(); c->d_stats.release(); c->d_raybuf.release();
@@ -278,7 +278,8 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     c->instance_count = s->instance_count;
     c->tri_count = (uint32_t)tri_total;
     const size_t n = c->tri_count ? c->tri_count : 1;
-    HIP_OR_FAIL(c, c->d_nodes.alloc(n * 8));
+    HIP_OR_FAIL(c, c->d_nodes.alloc(n * 4));
+    HIP_OR_FAIL(c, c->d_wide_bref.alloc(n));
     HIP_OR_FAIL(c, c->d_bin_child.alloc(n));
     HIP_OR_FAIL(c, c->d_bin_range.alloc(n));
     HIP_OR_FAIL(c, c->d_deposit.alloc(n * 8));
@@ -392,7 +393,7 @@ int vkr_bvh_download(vkr_ctx* c, float* nodes, float* tris)
     if (int rc = set_device(c)) return rc;
     HIP_OR_FAIL(c, hipDeviceSynchronize());
     size_t nn = c->wide_count;
-    if (nodes && nn) HIP_OR_FAIL(c, hipMemcpy(nodes, c->d_nodes.p, nn * 128, hipMemcpyDeviceToHost));
+    if (nodes && nn) HIP_OR_FAIL(c, hipMemcpy(nodes, c->d_nodes.p, nn * 64, hipMemcpyDeviceToHost));
     if (tris && c->tri_count) HIP_OR_FAIL(c, hipMemcpy(tris, c->d_tris.p, (size_t)c->tri_count * 48, hipMemcpyDeviceToHost));
     return VKR_OK;
 }

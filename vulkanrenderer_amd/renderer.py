@@ -154,7 +154,7 @@ class RayTracingContext:
 
     def download(self):
         info = self.info()
-        nodes = np.zeros((max(1, info.node_count), 32), dtype=np.float32)
+        nodes = np.zeros((max(1, info.node_count), 16), dtype=np.float32)
         tris = np.zeros((max(1, info.triangle_count), 12), dtype=np.float32)
         c = self.ctx
         _check(c.handle, c.lib.vkr_bvh_download(c.handle, nodes.ctypes.data, tris.ctypes.data), "vkr_bvh_download")
