@@ -186,29 +186,33 @@ class OracleScene:
         n = valid.size
         out = np.zeros(valid.shape, dtype=np.float32)
         l = _f32(L3)
-        self.L.orc_shadow_sun(self.handle, _p(_f32(wp)), _p(_f32(ng)), _p(np.ascontiguousarray(valid)), n, _p(l),
-                              float(radius), float(samples), _p(out))
+        wpa, nga, va = _f32(wp), _f32(ng), np.ascontiguousarray(valid, dtype=np.uint8)
+        self.L.orc_shadow_sun(self.handle, _p(wpa), _p(nga), _p(va), n, _p(l), float(radius), float(samples), _p(out))
         return out
 
     def shadow_point(self, wp, ng, valid, P3):
         n = valid.size
         out = np.zeros(valid.shape, dtype=np.float32)
         p = _f32(P3)
-        self.L.orc_shadow_point(self.handle, _p(_f32(wp)), _p(_f32(ng)), _p(np.ascontiguousarray(valid)), n, _p(p), _p(out))
+        wpa, nga, va = _f32(wp), _f32(ng), np.ascontiguousarray(valid, dtype=np.uint8)
+        self.L.orc_shadow_point(self.handle, _p(wpa), _p(nga), _p(va), n, _p(p), _p(out))
         return out
 
     def query_ao(self, o, d, tmin, tmax):
         t = C.c_float()
-        hit = self.L.orc_query_ao(self.handle, _p(_f32(o)), _p(_f32(d)), tmin, tmax, C.byref(t))
+        oa, da = _f32(o), _f32(d)
+        hit = self.L.orc_query_ao(self.handle, _p(oa), _p(da), tmin, tmax, C.byref(t))
         return bool(hit), float(t.value)
 
     def trace_ao_ray(self, o, d, tmin, tmax):
         occ = C.c_int()
-        v = self.L.orc_trace_ao_ray(self.handle, _p(_f32(o)), _p(_f32(d)), tmin, tmax, C.byref(occ))
+        oa, da = _f32(o), _f32(d)
+        v = self.L.orc_trace_ao_ray(self.handle, _p(oa), _p(da), tmin, tmax, C.byref(occ))
         return float(v), int(occ.value)
 
     def shadow_ray(self, o, d):
-        return float(self.L.orc_shadow_ray(self.handle, _p(_f32(o)), _p(_f32(d))))
+        oa, da = _f32(o), _f32(d)
+        return float(self.L.orc_shadow_ray(self.handle, _p(oa), _p(da)))
 
 
 def atrous(ubo, step, src, depth, normal, y0=0, y1=None):
