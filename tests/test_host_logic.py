@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference interface: scenes, FrameState (FrameManager UBO bookkeeping), Rendergraph."""
+import numpy as np
+import pytest
+import torch
+
+import vulkanrenderer_amd as V
+from vulkanrenderer_amd import renderer as R
+from vulkanrenderer_amd import scenes as S
+
+
+def test_scene_generation_is_deterministic():
+    a, b = S.make_test_scene(), S.make_test_scene()
+    assert a.triangle_count() == b.triangle_count() > 500
+    assert np.array_equal(a.instance_mesh, b.instance_mesh) and np.array_equal(a.instance_transform, b.instance_transform)
+    for ma, mb in zip(a.meshes, b.meshes):
+        assert np.array_equal(ma.vertices, mb.vertices) and np.array_equal(ma.indices, mb.indices)
+    c = S.make_test_scene(seed=8)
+    assert not np.array_equal(a.instance_transform, c.instance_transform)
+
+
+def test_scene_has_all_material_classes():
+    sc = S.make_test_scene()
+    fr = sc.class_fractions()
+    assert set(fr) == {'opaque', 'mask', 'blend'} and abs(sum(fr.values()) - 1.0) < 1e-6 and all(f > 0 for f in fr.values())
+    flags = sc.mesh_opaque_flags()
+    assert set(np.unique(flags)) == {0, 1}
+    mp = sc.material_params()
+    assert mp.shape == (S.MAX_MATERIALS, 4) and mp.dtype == np.float32
+
+
+def test_vertex_layout_matches_reference_vertex_struct():
+    # Vertex = pos3 color3 normal3 uv2 tangent4 = 15 floats / 60 B, texCoord at byte 36 (RayTracingContext.cpp:262-264)
+    m = S.box_mesh(1, 0)
+    assert m.vertices.shape[1] == S.VERTEX_FLOATS == 15 and S.VERTEX_STRIDE == 60 and S.UV_OFFSET_FLOATS == 9
+    assert m.indices.dtype == np.uint32 and m.indices.size % 3 == 0 and m.indices.max() < m.vertices.shape[0]
+
+
+def test_frame_state_prev_view_proj_and_frame_index():
+    fs = S.FrameState(64, 36, ray_count=4)
+    u0 = fs.update((0, 1, 0), (0, 1, 10))
+    assert np.array_equal(u0[S.UBO_PREV_VIEW_PROJ:S.UBO_PREV_VIEW_PROJ + 16], np.eye(4, dtype=np.float32).reshape(16))
+    assert u0[S.UBO_RTAO_PARAMS1 + 3] == 0.0 and u0[S.UBO_RTAO_PARAMS0 + 1] == 4.0
+    u1 = fs.update((0, 1, 0.1), (0, 1, 10.1))
+    assert u1[S.UBO_RTAO_PARAMS1 + 3] == 1.0
+    view0 = u0[16:32].reshape(4, 4).T
+    proj0 = u0[32:48].reshape(4, 4).T
+    assert np.array_equal(u1[S.UBO_PREV_VIEW_PROJ:S.UBO_PREV_VIEW_PROJ + 16], S.col_major(proj0 @ view0))
+    fs.reset()
+    u2 = fs.update((0, 1, 0), (0, 1, 10))
+    assert np.array_equal(u2, u0)
+
+
+def test_projection_conventions():
+    p = S.perspective_rh_zo_yflip(45.0, 16 / 9, 0.1, 1000.0)
+    assert p[1, 1] < 0 and p[3, 2] == -1.0                       # Camera.cpp:151 Y flip, RH
+    near = p @ np.array([0, 0, -0.1, 1], dtype=np.float32)
+    far = p @ np.array([0, 0, -1000.0, 1], dtype=np.float32)
+    assert abs(near[2] / near[3]) < 1e-6 and abs(far[2] / far[3] - 1.0) < 1e-4   # depth zero-to-one
+    v = S.look_at_rh((1, 2, 3), (1, 2, -5))
+    assert np.allclose(v @ np.array([1, 2, 3, 1], dtype=np.float32), [0, 0, 0, 1], atol=1e-6)
+
+
+def test_sun_direction_is_minus_normalised_light_dir():
+    u = S.FrameState(8, 8).update((0, 0, 0), (0, 0, 1))
+    L = S.FrameState.sun_dir_to_light(u)
+    assert abs(float(np.linalg.norm(L)) - 1.0) < 1e-6 and L[1] > 0
+
+
+class _P(R.RenderPass):
+    def __init__(self, name, i, o, log):
+        super().__init__(name, i, o)
+        self.log = log
+
+    def render(self, ctx):
+        self.log.append(self.name)
+
+
+def test_rendergraph_orders_by_resource_names():
+    log = []
+    g = R.Rendergraph()
+    g.AddPass(_P("Forward", ["rtao_full", "depth"], ["scene_color"], log))
+    g.AddPass(_P("Rtao", ["depth"], ["rtao_full"], log))
+    g.AddPass(_P("DepthPrepass", [], ["depth", "normal"], log))
+    with pytest.raises(RuntimeError, match="before Compile"):
+        g.Execute(R.PassExecuteContext())
+    g.Compile()
+    g.Execute(R.PassExecuteContext())
+    assert log == ["DepthPrepass", "Rtao", "Forward"]
+
+
+def test_rendergraph_detects_cycles():
+    g = R.Rendergraph()
+    g.AddPass(_P("A", ["b"], ["a"], []))
+    g.AddPass(_P("B", ["a"], ["b"], []))
+    with pytest.raises(RuntimeError, match="cycle"):
+        g.Compile()
+
+
+def test_render_pass_template_method_order():
+    calls = []
+
+    class T(R.RenderPass):
+        def beginPass(self, c): calls.append("begin")
+        def render(self, c): calls.append("render")
+        def endPass(self, c): calls.append("end")
+
+    T("t", [], []).execute(R.PassExecuteContext())
+    assert calls == ["begin", "render", "end"]
+    with pytest.raises(NotImplementedError):
+        R.RenderPass("x", [], []).execute(R.PassExecuteContext())
+
+
+def test_rtao_pass_declares_reference_resources():
+    # RtaoComputePass.cpp:16-25: inputs {"depth"}, outputs {"rtao_full"}; inspected without constructing a context
+    consts = R.RtaoComputePass.__init__.__code__.co_consts
+    assert "RtaoComputePass" in consts and "depth" in consts and "rtao_full" in consts
+    assert issubclass(R.RtaoComputePass, R.RenderPass)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_context_fails_loudly_without_a_gpu():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        R.Context(64, 36)
+
+
+def test_scene_to_desc_marshals_every_mesh_and_instance():
+    sc = S.make_material_matrix_scene()
+    desc, keep = R.scene_to_desc(sc)
+    assert desc.mesh_count == 5 and desc.instance_count == 8
+    assert desc.meshes[1].material_index == 1 and desc.meshes[1].opaque == 0 and desc.meshes[0].opaque == 1
+    assert desc.meshes[0].position_stride == 60 and desc.meshes[0].uv_stride == 60
+    assert desc.meshes[0].uvs - desc.meshes[0].positions == 36
+    assert desc.alpha_textures[1].width == 8 and desc.alpha_textures[0].alpha is None
+    assert list(desc.instances[1].transform)[3] == 0.0 and list(desc.instances[1].transform)[11] == 2.0
+
+
+def test_public_package_surface():
+    for name in ["Context", "RayTracingContext", "RtaoComputePass", "ShadowRays", "Rendergraph", "RenderPass",
+                 "PassExecuteContext", "FrameState", "make_bistro_class", "make_sponza_class", "bands"]:
+        assert hasattr(V, name), name

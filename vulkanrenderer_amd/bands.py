@@ -43,9 +43,10 @@ def pack_band(planes: Sequence[torch.Tensor], H: int, n: int, r: int, out: torch
 
 
 def all_gather_frame(packed: torch.Tensor, gathered: torch.Tensor, group=None) -> torch.Tensor:
-    """packed (PLANES, Hb, W) from every rank -> gathered (n, PLANES, Hb, W).  One collective per frame."""
+    """packed (PLANES, Hb, W) from every rank -> gathered (n, PLANES, Hb, W).  One collective per frame.
+    The payload travels as raw bytes: neither RCCL nor gloo has a 16-bit integer type, and no reduction is done."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_gather_into_tensor(gathered.view(-1), packed.view(-1), group=group)
+        dist.all_gather_into_tensor(gathered.view(-1).view(torch.uint8), packed.view(-1).view(torch.uint8), group=group)
     else:
         gathered.view(-1)[: packed.numel()].copy_(packed.view(-1))
     return gathered
