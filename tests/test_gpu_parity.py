@@ -2,8 +2,11 @@
 
 Bar (BASELINE.json north_star): per-ray hit/miss identical except grazing rays; final AO <= 0.5 % of pixels
 differing by > 1/255, max-abs stated.  Because both sides implement the same numeric contract the
-tests additionally report -- and for the pure-arithmetic kernels require -- bit-exact R16F outputs.
+tests additionally require bit-exact R16F outputs and zero ray mismatches; the north-star tolerances are asserted
+first so a future contract relaxation fails on the right line.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -12,6 +15,7 @@ from helpers import compare_r16f, to_np_u16
 pytestmark = pytest.mark.gpu
 
 AO_TOL_FRAC = 0.005        # north_star: <= 0.5 % of pixels may differ by > 1/255
+ONE16 = np.float16(1.0).view(np.uint16)
 
 
 @pytest.fixture(scope="module")
@@ -21,7 +25,7 @@ def torch_mod():
     return torch
 
 
-def _setup(scene, W, H, rays, iters, torch, brute=False, want_mask=True):
+def _setup(scene, W, H, rays, iters, torch, brute=False, want_mask=True, **fs_kw):
     from oracle import oracle as O
     from vulkanrenderer_amd import FrameState
     from vulkanrenderer_amd.renderer import Context, RayTracingContext, GBuffer, RtaoComputePass
@@ -32,31 +36,300 @@ def _setup(scene, W, H, rays, iters, torch, brute=False, want_mask=True):
     gb = GBuffer(ctx)
     rpass = RtaoComputePass(ctx, gb, atrous_iterations=iters, want_hit_mask=want_mask)
     opass = O.OracleRtaoPass(osc, W, H, iters)
-    fs = FrameState(W, H, ray_count=rays)
+    fs = FrameState(W, H, ray_count=rays, **fs_kw)
     return O, osc, ctx, rt, gb, rpass, opass, fs
 
 
-def test_rtao_chain_small_scene_two_frames(torch_mod, oracle_mod):
-    torch = torch_mod
-    from vulkanrenderer_amd import make_street_scene, camera_path
+def _check_frame(tag, ctx, rpass, opass, ref_full, ref_mask):
+    got_full = to_np_u16(rpass.rtao_full)
+    hist = compare_r16f(to_np_u16(rpass.image(0)), opass.hist[opass.last_curr])
+    full = compare_r16f(got_full, ref_full)
+    ray_mismatch = 0
+    if ref_mask is not None:
+        got_mask = rpass.hit_mask.cpu().numpy().view(np.uint32)
+        ray_mismatch = int(np.unpackbits((got_mask ^ ref_mask).view(np.uint8)).sum())
+    print(f"{tag}: history {hist} rtao_full {full} ray hit/miss mismatches {ray_mismatch}")
+    assert hist["frac_gt_1_255"] <= AO_TOL_FRAC and full["frac_gt_1_255"] <= AO_TOL_FRAC
+    assert ray_mismatch == 0
+    assert hist["bit_mismatch"] == 0 and full["bit_mismatch"] == 0
+
+
+def _run_chain(scene, W, H, rays, iters, frames, torch, tag, **fs_kw):
+    from vulkanrenderer_amd import camera_path
     from vulkanrenderer_amd.renderer import PassExecuteContext
-    scene = make_street_scene(7, 0.02, "t")
-    W, H = 160, 90
-    O, osc, ctx, rt, gb, rpass, opass, fs = _setup(scene, W, H, 4, 2, torch)
+    O, osc, ctx, rt, gb, rpass, opass, fs = _setup(scene, W, H, rays, iters, torch, **fs_kw)
     assert rt.info().triangle_count == osc.triangle_count() == scene.triangle_count()
-    for frame, (eye, tgt) in enumerate(camera_path(scene, 3)):
+    for frame, (eye, tgt) in enumerate(camera_path(scene, frames)):
         ubo = fs.update(eye, tgt)
         depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
         gb.upload(depth, normal, wp, ng, valid)
         rpass.execute(PassExecuteContext(ubo=ubo))
         ctx.sync()
         ref_full, ref_mask = opass.execute(ubo, depth, normal, want_mask=True)
-        got_full = to_np_u16(rpass.rtao_full)
-        got_mask = rpass.hit_mask.cpu().numpy().view(np.uint32)
-        hist = compare_r16f(to_np_u16(rpass.image(0)), opass.hist[opass.last_curr])
-        full = compare_r16f(got_full, ref_full)
-        ray_mismatch = int(np.unpackbits((got_mask ^ ref_mask).view(np.uint8)).sum())
-        print(f"frame {frame}: history {hist} rtao_full {full} ray hit/miss mismatches {ray_mismatch}")
-        assert ray_mismatch == 0
-        assert hist["frac_gt_1_255"] <= AO_TOL_FRAC and full["frac_gt_1_255"] <= AO_TOL_FRAC
-        assert hist["bit_mismatch"] == 0 and full["bit_mismatch"] == 0
+        _check_frame(f"{tag} frame {frame}", ctx, rpass, opass, ref_full, ref_mask)
+    ctx.close()
+
+
+def test_rtao_chain_small_scene_three_frames(torch_mod, oracle_mod):
+    from vulkanrenderer_amd import make_street_scene
+    _run_chain(make_street_scene(7, 0.02, "t"), 160, 90, 4, 2, 3, torch_mod, "street160x90")
+
+
+def test_config0_sponza_class_640x360(torch_mod, oracle_mod):
+    """BASELINE.json configs[0]: Sponza 640x360, 4 rays/px + temporal + 2 A-Trous iterations (synthetic
+    sponza-class scene of the same size; the glTF itself is not in the image)."""
+    from vulkanrenderer_amd import make_sponza_class
+    _run_chain(make_sponza_class(), 640, 360, 4, 2, 2, torch_mod, "c0")
+
+
+@pytest.mark.parametrize("W,H,rays,iters", [(67, 45, 1, 1), (33, 17, 16, 5), (8, 8, 8, 4), (130, 7, 3, 3)])
+def test_ragged_sizes_ray_counts_and_iterations(torch_mod, oracle_mod, W, H, rays, iters):
+    from vulkanrenderer_amd import make_test_scene
+    _run_chain(make_test_scene(), W, H, rays, iters, 2, torch_mod, f"{W}x{H} r{rays} i{iters}")
+
+
+def test_ray_count_is_clamped_like_the_shader(torch_mod, oracle_mod):
+    # rtao_trace_half.comp:252 clamps rayCount to [1, 16]; 40 and 0 must behave as 16 and 1 on both sides
+    from vulkanrenderer_amd import make_test_scene
+    _run_chain(make_test_scene(), 40, 24, 40, 1, 1, torch_mod, "rays40")
+    _run_chain(make_test_scene(), 40, 24, 0, 1, 1, torch_mod, "rays0")
+
+
+def test_material_matrix_scene(torch_mod, oracle_mod):
+    # opaque / MASK above+below cutoff / BLEND in front of a wall (SURVEY 8c pin 6)
+    from vulkanrenderer_amd import make_material_matrix_scene
+    from vulkanrenderer_amd.renderer import PassExecuteContext
+    scene = make_material_matrix_scene()
+    W, H = 128, 48
+    O, osc, ctx, rt, gb, rpass, opass, fs = _setup(scene, W, H, 8, 1, torch_mod, radius=3.0)
+    scene.cameras = [((3.5, 0.5, -4.0), (3.5, 0.5, 2.0))]
+    ubo = fs.update(*scene.cameras[0])
+    depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+    assert valid.any()
+    gb.upload(depth, normal, wp, ng, valid)
+    rpass.execute(PassExecuteContext(ubo=ubo))
+    ctx.sync()
+    ref_full, ref_mask = opass.execute(ubo, depth, normal, want_mask=True)
+    _check_frame("material matrix", ctx, rpass, opass, ref_full, ref_mask)
+    ctx.close()
+
+
+def test_debug_taps_9_to_12(torch_mod, oracle_mod):
+    from vulkanrenderer_amd import make_test_scene, camera_path
+    from vulkanrenderer_amd.renderer import PassExecuteContext
+    scene = make_test_scene()
+    W, H = 96, 54
+    for mode in (9, 10, 11, 12):
+        O, osc, ctx, rt, gb, rpass, opass, fs = _setup(scene, W, H, 4, 2, torch_mod, debug_view=mode)
+        for frame, (eye, tgt) in enumerate(camera_path(scene, 2)):
+            ubo = fs.update(eye, tgt)
+            assert ubo[95] == float(mode)
+            depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+            gb.upload(depth, normal, wp, ng, valid)
+            rpass.execute(PassExecuteContext(ubo=ubo))
+            ctx.sync()
+            ref_full, ref_mask = opass.execute(ubo, depth, normal, want_mask=True)
+            _check_frame(f"debug {mode} frame {frame}", ctx, rpass, opass, ref_full, None)
+        ctx.close()
+
+
+def test_separate_dispatches_equal_execute(torch_mod, oracle_mod):
+    """RtaoComputePass::render = dispatchTrace + dispatchAtrous + dispatchUpsample (RtaoComputePass.cpp:503-571)."""
+    from vulkanrenderer_amd import make_test_scene, camera_path
+    from vulkanrenderer_amd.renderer import PassExecuteContext
+    scene = make_test_scene()
+    W, H = 96, 54
+    for iters in (1, 2, 3):
+        O, osc, ctx, rt, gb, rpass, opass, fs = _setup(scene, W, H, 4, iters, torch_mod)
+        ctx2 = type(ctx)(W, H)
+        rt2 = type(rt)(ctx2)
+        rt2.init(scene)
+        gb2 = type(gb)(ctx2)
+        rpass2 = type(rpass)(ctx2, gb2, atrous_iterations=iters)
+        for frame, (eye, tgt) in enumerate(camera_path(scene, 3)):
+            ubo = fs.update(eye, tgt)
+            depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+            gb.upload(depth, normal)
+            gb2.upload(depth, normal)
+            rpass.execute(PassExecuteContext(ubo=ubo))
+            rpass2.dispatchTrace(ubo)
+            rpass2.dispatchAtrous(ubo)
+            rpass2.dispatchUpsample(ubo)
+            rpass2.endFrame()
+            ctx.sync(); ctx2.sync()
+            assert np.array_equal(to_np_u16(rpass.rtao_full), to_np_u16(rpass2.rtao_full))
+            assert np.array_equal(to_np_u16(rpass.image(0)), to_np_u16(rpass2.image(0)))
+            # the final ping-pong image is the one index (iterations-1)%2 names (RtaoComputePass.cpp:560-561)
+            assert np.array_equal(to_np_u16(rpass.image(2 + (iters - 1) % 2)), to_np_u16(rpass2.image(2 + (iters - 1) % 2)))
+        ctx.close(); ctx2.close()
+
+
+def test_golden_vectors(torch_mod):
+    """HIP path against the committed fixture alone (tests/golden/rtao_64x36.npz): no oracle in the loop."""
+    import os
+    from vulkanrenderer_amd import make_street_scene
+    from vulkanrenderer_amd.renderer import (Context, GBuffer, PassExecuteContext, RayTracingContext, RtaoComputePass,
+                                             ShadowRays)
+    from vulkanrenderer_amd.scenes import FrameState
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rtao_64x36.npz"))
+    seed, W, H, rays, iters, frames = (int(x) for x in g["meta"])
+    scene = make_street_scene(seed, float(g["detail"][0]), "golden")
+    ctx = Context(W, H)
+    rt = RayTracingContext(ctx)
+    rt.init(scene)
+    gb = GBuffer(ctx)
+    rpass = RtaoComputePass(ctx, gb, atrous_iterations=iters, want_hit_mask=True)
+    sh = ShadowRays(ctx, gb)
+    tap_ctx = Context(W, H)
+    tap_rt = RayTracingContext(tap_ctx)
+    tap_rt.init(scene)
+    tap_gb = GBuffer(tap_ctx)
+    tap_pass = RtaoComputePass(tap_ctx, tap_gb, atrous_iterations=iters)
+    for f in range(frames):
+        ubo = g[f"ubo{f}"]
+        gb.upload(g[f"depth{f}"], g[f"normal{f}"], g[f"world_pos{f}"], g[f"geom_normal{f}"], g[f"valid{f}"])
+        rpass.execute(PassExecuteContext(ubo=ubo))
+        ctx.sync()
+        assert np.array_equal(to_np_u16(rpass.rtao_full), g[f"rtao_full{f}"])
+        assert np.array_equal(to_np_u16(rpass.image(0)), g[f"history{f}"])
+        assert np.array_equal(rpass.hit_mask.cpu().numpy().view(np.uint32), g[f"hit_mask{f}"])
+        fs_ubo = ubo.copy()
+        fs_ubo[56:58] = (0.01, 8.0)
+        sun = sh.sun(fs_ubo).cpu().numpy()
+        assert np.array_equal(sun.view(np.uint32), g[f"sun{f}"].view(np.uint32))
+        pt = sh.point(ubo, 0).cpu().numpy()
+        assert np.array_equal(pt.view(np.uint32), g[f"point{f}"].view(np.uint32))
+        tap_gb.upload(g[f"depth{f}"], g[f"normal{f}"])
+        for mode in (10, 11, 12):
+            u = ubo.copy()
+            u[95] = float(mode)
+            tap_pass.reset()
+            tap_pass.dispatchTrace(u)
+            tap_pass.endFrame()
+            tap_ctx.sync()
+            assert np.array_equal(to_np_u16(tap_pass.image(0)), g[f"tap{mode}_{f}"]), f"tap {mode} frame {f}"
+    ctx.close(); tap_ctx.close()
+
+
+def test_determinism_and_reset(torch_mod):
+    from vulkanrenderer_amd import make_test_scene, camera_path, FrameState
+    from vulkanrenderer_amd.renderer import (Context, GBuffer, PassExecuteContext, RayTracingContext, RtaoComputePass,
+                                             generate_gbuffer)
+    scene = make_test_scene()
+    W, H = 200, 120
+    ctx = Context(W, H)
+    rt = RayTracingContext(ctx)
+    rt.init(scene)
+    gb = GBuffer(ctx)
+    rpass = RtaoComputePass(ctx, gb, atrous_iterations=4)
+    runs = []
+    for rep in range(2):
+        fs = FrameState(W, H, ray_count=8)
+        rpass.reset()
+        outs = []
+        for eye, tgt in camera_path(scene, 3):
+            ubo = fs.update(eye, tgt)
+            generate_gbuffer(ctx, ubo, gb)
+            rpass.execute(PassExecuteContext(ubo=ubo))
+            ctx.sync()
+            outs.append(to_np_u16(rpass.rtao_full).copy())
+        runs.append(outs)
+        if rep == 0:
+            rt.rebuild()          # a rebuilt BVH must not change a single bit either
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    ao = runs[0][-1].view(np.float16).astype(np.float32)
+    assert ao.min() >= 0.0 and ao.max() <= 1.0 and ao.min() < 0.9
+    ctx.close()
+
+
+def test_all_sky_and_empty_scene(torch_mod, oracle_mod):
+    from vulkanrenderer_amd import FrameState, make_test_scene
+    from vulkanrenderer_amd.scenes import SceneData
+    from vulkanrenderer_amd.renderer import (Context, GBuffer, PassExecuteContext, RayTracingContext, RtaoComputePass,
+                                             ShadowRays, generate_gbuffer)
+    W, H = 64, 40
+    # (a) camera looking at the sky: every pixel invalid -> AO 1.0 everywhere, hit mask 0
+    scene = make_test_scene()
+    O, osc, ctx, rt, gb, rpass, opass, fs = _setup(scene, W, H, 4, 2, torch_mod)
+    ubo = fs.update((0.0, 50.0, 0.0), (0.0, 150.0, 0.1))
+    generate_gbuffer(ctx, ubo, gb)
+    rpass.execute(PassExecuteContext(ubo=ubo))
+    ctx.sync()
+    assert int(gb.valid.sum().item()) == 0
+    assert np.all(to_np_u16(rpass.rtao_full) == ONE16) and int(rpass.hit_mask.abs().sum().item()) == 0
+    ctx.close()
+    # (b) empty scene: builds, G-buffer is all sky, rays all miss, shadows fully lit
+    empty = SceneData([], [], np.zeros(0, dtype=np.uint32), np.zeros((0, 12), dtype=np.float32), "empty")
+    ctx = Context(W, H)
+    rt = RayTracingContext(ctx)
+    rt.init(empty)
+    info = rt.info()
+    assert info.triangle_count == 0 and info.node_count == 0
+    gb = GBuffer(ctx)
+    fs = FrameState(W, H, ray_count=4)
+    ubo = fs.update((0, 1, 0), (0, 1, 5))
+    generate_gbuffer(ctx, ubo, gb)
+    assert int(gb.valid.sum().item()) == 0
+    # a synthetic floor G-buffer over the empty BVH: all AO rays miss -> visibility 1
+    oscf = O.OracleScene(make_test_scene())
+    depth, normal, wp, ng, valid = oscf.gbuffer(ubo, W, H)
+    gb.upload(depth, normal, wp, ng, valid)
+    rpass = RtaoComputePass(ctx, gb, atrous_iterations=2, want_hit_mask=True)
+    rpass.execute(PassExecuteContext(ubo=ubo))
+    ctx.sync()
+    assert np.all(to_np_u16(rpass.rtao_full) == ONE16) and int(rpass.hit_mask.abs().sum().item()) == 0
+    sh = ShadowRays(ctx, gb)
+    assert float(sh.sun(ubo).min().item()) == 1.0 and float(sh.point(ubo, 0).min().item()) == 1.0
+    oe = O.OracleScene(empty)
+    ref = O.OracleRtaoPass(oe, W, H, 2).execute(ubo, depth, normal)
+    assert np.array_equal(ref, to_np_u16(rpass.rtao_full))
+    rt.updateTopLevelAS(empty.instance_mesh, empty.instance_transform)     # refit of nothing is a no-op
+    ctx.close()
+
+
+def test_single_triangle_scene(torch_mod, oracle_mod):
+    from vulkanrenderer_amd.scenes import Material, Mesh, SceneData, _make_vertices, trs
+    from vulkanrenderer_amd.renderer import PassExecuteContext
+    pos = np.array([[-5, 0, -5], [5, 0, -5], [0, 0, 8]], dtype=np.float32)
+    floor = Mesh(_make_vertices(pos, np.zeros((3, 2), dtype=np.float32)), np.array([0, 2, 1], dtype=np.uint32), 0)
+    scene = SceneData([floor], [Material()], np.array([0], dtype=np.uint32), np.stack([trs()]).astype(np.float32), "tri")
+    W, H = 48, 32
+    O, osc, ctx, rt, gb, rpass, opass, fs = _setup(scene, W, H, 4, 2, torch_mod)
+    assert rt.info().triangle_count == 1
+    ubo = fs.update((0.0, 2.0, -3.0), (0.0, 0.0, 2.0))
+    depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+    assert valid.any()
+    gb.upload(depth, normal, wp, ng, valid)
+    rpass.execute(PassExecuteContext(ubo=ubo))
+    ctx.sync()
+    ref_full, ref_mask = opass.execute(ubo, depth, normal, want_mask=True)
+    _check_frame("single triangle", ctx, rpass, opass, ref_full, ref_mask)
+    ctx.close()
+
+
+def test_gbuffer_primary_matches_oracle(torch_mod, oracle_mod):
+    from vulkanrenderer_amd import make_street_scene, camera_path, FrameState
+    from vulkanrenderer_amd.renderer import Context, GBuffer, RayTracingContext, generate_gbuffer
+    from oracle import oracle as O
+    scene = make_street_scene(11, 0.03, "gb")
+    W, H = 192, 108
+    osc = O.OracleScene(scene)
+    ctx = Context(W, H)
+    rt = RayTracingContext(ctx)
+    rt.init(scene)
+    gb = GBuffer(ctx)
+    fs = FrameState(W, H)
+    for eye, tgt in camera_path(scene, 2, step=3.0):
+        ubo = fs.update(eye, tgt)
+        generate_gbuffer(ctx, ubo, gb)
+        ctx.sync()
+        depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+        assert np.array_equal(gb.valid.cpu().numpy(), valid)
+        # closest-hit ties between coplanar/abutting triangles may resolve to a different primitive: report them
+        dm = (to_np_u16(gb.linear_depth) != depth).mean()
+        nm = (to_np_u16(gb.normal) != normal).any(axis=-1).mean()
+        print(f"gbuffer mismatches: depth {dm:.5f} normal {nm:.5f}")
+        assert dm == 0.0 and nm <= 0.001
+        assert np.abs(gb.world_pos.cpu().numpy() - wp).max() <= 1e-4
+    ctx.close()

@@ -90,6 +90,7 @@ struct vkr_ctx {
     uint32_t morton_bits = 21;
     uint32_t bvh_height = 0;
     uint32_t wide_count = 0, wide_levels = 0;
+    bool bounds_dirty = false;
     vkr::DevBuf<float4> d_nodes;             // 4 x float4 per wide node (traverse.hpp)
     vkr::DevBuf<uint4> d_wide_bref;          // per wide node: binary refs of its children (refit only)
     vkr::DevBuf<int2> d_bin_child;           // binary LBVH (build/refit only)

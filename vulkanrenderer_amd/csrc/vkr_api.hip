@@ -312,6 +312,7 @@ static int read_height_and_bounds(vkr_ctx* c, hipStream_t st)
     HIP_OR_FAIL(c, hipMemcpyAsync(&b, c->d_bounds.p, sizeof(b), hipMemcpyDeviceToHost, st));
     HIP_OR_FAIL(c, hipStreamSynchronize(st));
     c->bvh_height = h;
+    c->bounds_dirty = false;
     for (int k = 0; k < 3; ++k) { c->bounds_min[k] = dec_f(b.tri_min[k]); c->bounds_max[k] = dec_f(b.tri_max[k]); }
     return VKR_OK;
 }
@@ -326,7 +327,18 @@ int vkr_bvh_build(vkr_ctx* c, void* stream)
     c->bvh_height = 0;
     c->wide_count = 0;
     c->wide_levels = 0;
-    if (c->tri_count == 0) { c->has_bvh = true; return VKR_OK; }
+    if (c->tri_count == 0) {
+        // empty scene (RayTracingContext::init with no instances): a root whose four slots are all unused, stored
+        // inverted (qmin = 255, qmax = 0, unit scale) so every slab test fails by itself and all rays miss
+        const uint32_t none = (uint32_t)VKR_CHILD_NONE;
+        const uint32_t root[16] = {0u, 0u, 0u, 127u | (127u << 8) | (127u << 16),
+                                   0xffffffffu, 0xffffffffu, 0xffffffffu, 0u,
+                                   0u, 0u, 0u, 0u, none, none, none, none};
+        HIP_OR_FAIL(c, hipMemcpyAsync(c->d_nodes.p, root, sizeof(root), hipMemcpyHostToDevice, st));
+        HIP_OR_FAIL(c, hipStreamSynchronize(st));
+        c->has_bvh = true;
+        return VKR_OK;
+    }
     // 21 bits/axis; if the wide tree comes out deeper than the traversal stack allows (pathological duplicate
     // centroids), fall back to 10 bits/axis where the index tie-break bounds the height by 30 + log2(n).
     const uint32_t tries[2] = {21u, 10u};
@@ -369,6 +381,7 @@ int vkr_bvh_refit(vkr_ctx* c, const vkr_instance* inst, uint32_t count, void* st
     }
     if (c->tri_count == 0) return VKR_OK;
     HIP_OR_FAIL(c, bvh_build_launch(c, true, st));
+    c->bounds_dirty = true;   // the refit recomputed the scene bounds on the device; info_get fetches them on demand
     return VKR_OK;
 }
 
@@ -377,6 +390,14 @@ int vkr_bvh_info_get(vkr_ctx* c, vkr_bvh_info* out)
     if (!c) return VKR_ERR_INVALID_ARG;
     if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
     if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "no BVH");
+    if (c->bounds_dirty) {
+        if (int rc = set_device(c)) return rc;
+        BvhBounds b;
+        HIP_OR_FAIL(c, hipDeviceSynchronize());
+        HIP_OR_FAIL(c, hipMemcpy(&b, c->d_bounds.p, sizeof(b), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3; ++k) { c->bounds_min[k] = dec_f(b.tri_min[k]); c->bounds_max[k] = dec_f(b.tri_max[k]); }
+        c->bounds_dirty = false;
+    }
     out->triangle_count = c->tri_count;
     out->node_count = c->wide_count;
     out->height = c->wide_levels;

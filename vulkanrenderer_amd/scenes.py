@@ -310,7 +310,7 @@ def make_bistro_class(seed: int = 0xB1572026) -> SceneData:
 
 
 def make_sponza_class(seed: int = 0x5907A) -> SceneData:
-    return make_street_scene(seed, 0.105, "sponza-class")
+    return make_street_scene(seed, 0.26, "sponza-class")     # ~257 k triangles (Sponza glTF: ~262 k)
 
 
 def make_test_scene(seed: int = 7, detail: float = 0.004) -> SceneData:
