@@ -161,11 +161,16 @@ typedef struct vkr_bvh_info {
 VKR_API int vkr_bvh_info_get(vkr_ctx* ctx, vkr_bvh_info* out);
 
 /* Debug/inspection copies of the BVH to HOST memory for structural tests (no reference counterpart:
- * the Vulkan AS is opaque).  nodes: node_count x 32 floats
- * {minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4], child[4](bits), build refs[4](bits)};
- * child >= 0: wide node; child < 0: leaf, x = ~child, first = x & 0x0fffffff, count = ((x>>28)&7)+1;
- * 0x7fffffff: unused slot.  Root = node 0.
- * tris: triangle_count x 12 floats {v0 xyz, mesh|class<<28 (bits), e1 xyz, prim(bits), e2 xyz, flat id(bits)}. */
+ * the Vulkan AS is opaque).  nodes: node_count x 16 words (64 B, the record the traversal reads):
+ *   w0-2  origin xyz (float)        w3  ex | ey<<8 | ez<<16 | child_count<<24   (biased exponents)
+ *   w4-6  qmin x/y/z, one byte per child slot (slot c in bits 8c..8c+7)
+ *   w7-9  qmax x/y/z, same packing   w10-11 zero
+ *   w12-15 child refs: >= 0 wide node; < 0 leaf, x = ~ref, first = x & 0x0fffffff, count = ((x>>28)&7)+1;
+ *          0x7fffffff unused slot (stored with qmin = 255, qmax = 0 so it can never be hit).
+ *   slot box: min = origin + qmin * 2^(e-127), max = origin + qmax * 2^(e-127) (conservative).  Root = node 0.
+ * tris: triangle_count x 12 floats {v0 xyz, mesh|class<<28 (bits), e1 xyz, prim(bits), e2 xyz, flat id(bits)},
+ *   class 0 = commits, 1 = BLEND (never occludes AO), 2 = MASK (alpha test); flat id = position in
+ *   instance-major, mesh-triangle-minor order. */
 VKR_API int vkr_bvh_download(vkr_ctx* ctx, float* nodes, float* tris);
 
 /* ---------------------------------------------------------------- RTAO pass ------------- */
@@ -190,7 +195,7 @@ VKR_API int vkr_rtao_execute(vkr_ctx* ctx, const vkr_rtao_frame_io* io, void* st
 /* Row-band variant for multi-GPU (no reference counterpart: the reference is single-GPU).  Produces rows
  * [y0, y1) of rtao_full and of history[curr]; rows outside are untouched.  Internally traces and filters the
  * A-Trous halo (2*(2^N - 1) rows each side) so the band is bit-identical to the same rows of a full-frame
- * vkr_rtao_execute.  The caller all-gathers the bands (history via vkr_rtao_history) before the next frame. */
+ * vkr_rtao_execute.  The caller all-gathers the bands (history via vkr_rtao_image(ctx, 0)) before the next frame. */
 VKR_API int vkr_rtao_execute_band(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t y0, uint32_t y1, void* stream);
 
 /* The three dispatches, individually callable (RtaoComputePass.cpp:503-517, 519-554, 556-571).
@@ -244,7 +249,7 @@ typedef struct vkr_trace_stats {
     uint64_t tris_tested;   /* ray/triangle tests                           */
     uint64_t wave_node_iters; /* node-loop iterations counted once per wave (lane utilisation = nodes_visited / (64*this)) */
     uint64_t wave_tri_iters;  /* triangle-loop iterations counted once per wave */
-    uint64_t overflow_tiles;  /* 8x8 tiles handed to the generic kernel because a short stack overflowed */
+    uint64_t overflow_tiles;  /* reserved (always 0): deep rays spill to per-lane scratch inside the same kernel */
 } vkr_trace_stats;
 /* Enable (1) / disable (0) traversal counters for subsequent AO traces (slower kernel variant), and read
  * them back (synchronises).  Feeds bench.py's algorithmic-bytes figure. */
