@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+T_START = time.perf_counter()
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -96,15 +98,28 @@ def cpu_baseline(scene, wl, ubos, gb0_depth, gb0_normal, target_seconds):
                       f"one A-Trous iteration on the same rows {dta * 1e3:.0f} ms"}
 
 
+def log(msg):
+    if os.environ.get("VKR_BENCH_VERBOSE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - T_START:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = max(1, args.gpus)
+    # VKR_BENCH_REHEARSE=1: functional rehearsal of the N>1 path on a one-GPU box (all ranks share cuda:0, gloo
+    # instead of RCCL).  Its timings mean nothing; the driver's multi-GPU runs never set it.
+    rehearse = os.environ.get("VKR_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert world == n, f"--gpus {n} but WORLD_SIZE {world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -120,7 +135,9 @@ def main():
     K, Wu = args.steps, args.warmup
     frames = K + Wu
 
+    log(f"workload {wl_name}, generating scene")
     scene = make_scene(scene_kind)
+    log("scene ready")
     if os.environ.get("VKR_BENCH_ALL_OPAQUE"):      # experiment switch: cost of the MASK/BLEND candidate path
         for m in scene.materials:
             m.alpha_mode = 0
@@ -131,6 +148,7 @@ def main():
     ctx.sync()
     first_build_s = time.perf_counter() - t0
     info = rt.info()
+    log(f"BVH built: {info.triangle_count} triangles")
     # LBVH build, timed separately (config names it): rebuild 3x on the resident scene, HIP-event timed
     build_ms = min(event_time_ms(rt.rebuild, None) for _ in range(3))
 
@@ -144,6 +162,7 @@ def main():
         gbs.append(gb)
     ctx.sync()
 
+    log("G-buffers ready")
     rpass = RtaoComputePass(ctx, gbs[0], atrous_iterations=iters)
     y0, y1 = bands.band_rows(H, n, rank)
     if n > 1:
@@ -170,6 +189,7 @@ def main():
 
     for i in range(Wu):
         step(i)
+        log(f"warmup step {i} issued")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -182,6 +202,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f} s")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
