@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvkr_rt.so")
+# VKR_LIB_PATH: experiment hook (tools/variants.sh) to load a differently-built copy of the same library
+LIB_PATH = os.environ.get("VKR_LIB_PATH") or os.path.join(_HERE, "lib", "libvkr_rt.so")
 
 VKR_OK, VKR_ERR_INVALID_ARG, VKR_ERR_STATE, VKR_ERR_HIP, VKR_ERR_OOM, VKR_ERR_LIMIT = range(6)
 MAX_MATERIALS = 256

@@ -130,12 +130,13 @@ VKR_DI uint64_t expand3(uint64_t x)
     return x;
 }
 
-__global__ __launch_bounds__(256) void k_morton(BuildIn in, const BvhBounds* bnd, uint32_t bits, uint64_t* keys,
+__global__ __launch_bounds__(256) void k_morton(BuildIn in, const BvhBounds* bnd, uint32_t bits, int emc, uint64_t* keys,
                                                 uint32_t* vals)
 {
     uint32_t flat = blockIdx.x * 256u + threadIdx.x;
     if (flat >= in.tri_count) return;
     TriW t = emit_tri(in, flat);
+    const float tv[3][3] = {{t.v0.x, t.v1.x, t.v2.x}, {t.v0.y, t.v1.y, t.v2.y}, {t.v0.z, t.v1.z, t.v2.z}};
     float c[3];
     c[0] = (__builtin_fminf(t.v0.x, __builtin_fminf(t.v1.x, t.v2.x)) + __builtin_fmaxf(t.v0.x, __builtin_fmaxf(t.v1.x, t.v2.x))) * 0.5f;
     c[1] = (__builtin_fminf(t.v0.y, __builtin_fminf(t.v1.y, t.v2.y)) + __builtin_fmaxf(t.v0.y, __builtin_fmaxf(t.v1.y, t.v2.y))) * 0.5f;
@@ -152,7 +153,32 @@ __global__ __launch_bounds__(256) void k_morton(BuildIn in, const BvhBounds* bnd
         uint32_t v = (s > 0.0f) ? (uint32_t)s : 0u;   // NaN -> 0
         q[k] = v > qmax ? qmax : v;
     }
-    keys[flat] = (expand3(q[0]) << 2) | (expand3(q[1]) << 1) | expand3(q[2]);
+    if (emc) {
+        // Extended Morton code (Vinkler, Bittner, Havran 2017): a size component interleaved with x, y, z, so a
+        // triangle larger than the current cell leaves the spatial subdivision at that level and is grouped with
+        // the other large triangles of the cell instead of inflating the boxes of its small neighbours.
+        float srel = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float lo = dec_f(bnd->cen_min[k]), hi = dec_f(bnd->cen_max[k]);
+            float ext = hi - lo;
+            float tlo = __builtin_fminf(tv[k][0], __builtin_fminf(tv[k][1], tv[k][2]));
+            float thi = __builtin_fmaxf(tv[k][0], __builtin_fmaxf(tv[k][1], tv[k][2]));
+            float r = (ext > 0.0f) ? (thi - tlo) / ext : 0.0f;
+            srel = __builtin_fmaxf(srel, r);
+        }
+        float sf = srel * scale;
+        uint32_t sq = (sf > 0.0f) ? (uint32_t)sf : 0u;
+        if (sq > qmax) sq = qmax;
+        uint64_t key = 0;
+        for (int b = (int)bits - 1; b >= 0; --b) {
+            key = (key << 4) | (((q[0] >> b) & 1ull) << 3) | (((q[1] >> b) & 1ull) << 2) | (((q[2] >> b) & 1ull) << 1) |
+                  ((uint64_t)(sq >> b) & 1ull);
+        }
+        keys[flat] = key;
+    } else {
+        keys[flat] = (expand3(q[0]) << 2) | (expand3(q[1]) << 1) | expand3(q[2]);
+    }
     vals[flat] = flat;
 }
 
@@ -624,9 +650,11 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     k_bounds_init<<<1, 64, 0, st>>>(c->d_bounds.p);   // also on refit: transforms move the scene, and the
     k_bounds<<<nb, 256, 0, st>>>(in, c->d_bounds.p);   // conservative padding scales with its extent
     if (!refit_only) {
-        k_morton<<<nb, 256, 0, st>>>(in, c->d_bounds.p, c->morton_bits, c->d_keys[0].p, c->d_vals[0].p);
+        const int emc = c->morton_emc ? 1 : 0;
+        const uint32_t mbits = emc ? (c->morton_bits > 15u ? 15u : c->morton_bits) : c->morton_bits;
+        k_morton<<<nb, 256, 0, st>>>(in, c->d_bounds.p, mbits, emc, c->d_keys[0].p, c->d_vals[0].p);
         const uint32_t ntiles = (n + RS_TILE - 1) / RS_TILE;
-        const int key_bits = 3 * (int)c->morton_bits;
+        const int key_bits = (emc ? 4 : 3) * (int)mbits;
         int cur = 0;
         for (int shift = 0; shift < key_bits; shift += 8) {
             k_rs_hist<<<ntiles, RS_THREADS, 0, st>>>(c->d_keys[cur].p, n, shift, ntiles, c->d_hist.p);

@@ -91,6 +91,7 @@ struct vkr_ctx {
     uint32_t bvh_height = 0;
     uint32_t wide_count = 0, wide_levels = 0;
     bool bounds_dirty = false;
+    bool morton_emc = false;   // extended Morton codes (size component), see k_morton
     vkr::DevBuf<float4> d_nodes;             // 4 x float4 per wide node (traverse.hpp)
     vkr::DevBuf<uint4> d_wide_bref;          // per wide node: binary refs of its children (refit only)
     vkr::DevBuf<int2> d_bin_child;           // binary LBVH (build/refit only)

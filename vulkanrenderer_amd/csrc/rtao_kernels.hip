@@ -344,6 +344,10 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
         bool active = false, found = false, retried = false;
         uint32_t spill[2 * (VKR_MAX_STACK - VKR_LDS_STACK)];   // scratch: touched only by rays deeper than the LDS part
         int cur = CUR_DONE;
+        // Postponed leaves (after Aila & Laine's speculative traversal, depth 2): a lane that reaches a leaf parks it
+        // and keeps walking nodes, so node steps and triangle steps both run fuller.  Closest-hit results do not
+        // depend on the visiting order.
+        int pend0 = CUR_DONE, pend1 = CUR_DONE;
         uint32_t sp = 0;
         V3 ro = v3(0, 0, 0), rdir = v3(0, 0, 1), id = v3(0, 0, 0);
         float tmin = 0.0f, tmin0 = 0.0f, tmax = 0.0f, tbest = 0.0f, adv = 0.0f;
@@ -356,12 +360,13 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
         for (;;) {
             // ---- service finished rays and pull new ones, in batches: doing this the moment any single lane
             // finishes would run ~100 instructions at 1/64 utilisation per ray.
-            const unsigned long long donem = __ballot(active && cur == CUR_DONE);
+            const bool ray_done = active && cur == CUR_DONE && pend0 == CUR_DONE;
+            const unsigned long long donem = __ballot(ray_done);
             const unsigned long long idlem = __ballot(!active);
             const int n_serv = __popcll(donem) + ((next < total) ? __popcll(idlem) : 0);
             if ((donem | idlem) == ~0ull || n_serv >= VKR_REFILL_BATCH) {
                 // a ray whose traversal ended: self-hit retry (:193-200) or result (:187-189,205-212)
-                if (active && cur == CUR_DONE) {
+                if (ray_done) {
                     if (found && !retried && tbest <= tmin0 * 1.5f) {
                         adv = gmax(tmin0 * 2.0f, 2e-4f);
                         ro = ro + rdir * adv;
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
             // wait for each other's loops to drain; the cheaper triangle step runs as soon as 1/VKR_LEAF_VOTE as
             // many lanes want it as want a node step.
             const int n_node = __popcll(__ballot(cur >= 0));
-            const int n_leaf = __popcll(__ballot(cur < 0 && cur != CUR_DONE));
+            const int n_leaf = __popcll(__ballot(pend0 != CUR_DONE));
             const float tb = tbest * 1.000001f;   // padded: culling may only err towards extra visits
             bool need_pop = false;
             if (n_leaf == 0 || n_leaf * VKR_LEAF_VOTE < n_node * VKR_LEAF_VOTE_DEN) {
@@ -464,9 +469,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
                     }
                     if (k0 != 0xffffffffu) cur = (int)r0; else need_pop = true;
                 }
-            } else if (cur < 0 && cur != CUR_DONE) {
+            } else if (pend0 != CUR_DONE) {
                 // ---- leaf: ONE triangle per step (queryAoClosestHit :125-182, closest committed hit)
-                uint32_t x = (uint32_t)(~cur);
+                uint32_t x = (uint32_t)(~pend0);
                 uint32_t first = x & 0x0fffffffu, rest = (x >> 28) & 7u;     // rest = triangles after this one
                 {
                     const float4* tp = (const float4*)(tri_base + (size_t)first * 48u);
@@ -488,8 +493,13 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
                     if (hit && cls == 2u) hit = alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), u, v);
                     if (hit) { tbest = t; found = true; }
                 }
-                if (rest != 0u) cur = (int)(~((first + 1u) | ((rest - 1u) << 28)));
-                else need_pop = true;
+                if (rest != 0u) pend0 = (int)(~((first + 1u) | ((rest - 1u) << 28)));
+                else { pend0 = pend1; pend1 = CUR_DONE; }
+            }
+            // ---- a leaf in hand moves to a free parking slot; the lane then continues with the next stack entry
+            if (cur < 0 && cur != CUR_DONE && pend1 == CUR_DONE) {
+                if (pend0 == CUR_DONE) pend0 = cur; else pend1 = cur;
+                need_pop = true;
             }
             // ---- next entry still in front of the closest hit (entries carry their tnear)
             if (need_pop) {

@@ -2,6 +2,7 @@
 // dispatch sequence and the shadow/G-buffer entry points.  Host code only; kernels live in the other files.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "internal.hpp"
@@ -112,6 +113,7 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     vkr_ctx* c = new vkr_ctx();
     c->device = desc->device;
     c->W = desc->width;
+    if (const char* e = getenv("VKR_MORTON_EMC")) c->morton_emc = (e[0] == '1');
     c->H = desc->height;
     auto bail = [&](int code, const char* what, hipError_t err) {
         fail(nullptr, code, "vkr_create: %s: %s", what, hipGetErrorString(err));
