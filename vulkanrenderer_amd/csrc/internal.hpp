@@ -112,7 +112,10 @@ struct vkr_ctx {
 
     // ---- RTAO images (FrameManager::createRtaoComputeTextures)
     vkr::DevBuf<uint16_t> d_hist_img[2], d_ping[2];
-    vkr::DevBuf<float4> d_raybuf;            // K1 ray slices: per wave (2 float4/ray + results), grow-only
+    vkr::DevBuf<float4> d_raybuf;            // K1 ray slices: per wave (2 float4/ray + retry list), grow-only
+    vkr::DevBuf<uint32_t> d_tile_counter;    // K1 persistent waves pull tiles from it
+    bool trace_streaming = true;             // K1 form: wave-wide queues (k_trace_q) or one ray per lane (k_trace)
+    int num_cus = 0;
     vkr::DevBuf<float4> d_nz;                // per-frame decoded normal.xyz + clamped depth (A-Trous operand)
     uint32_t frame_parity = 0;               // FrameManager currentFrame % 2
     uint32_t last_curr = 0;

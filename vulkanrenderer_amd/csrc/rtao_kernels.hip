@@ -537,21 +537,339 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
     resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc, visibility, mask);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K1, streaming form (the default).  Persistent waves pull 8x8 tiles from a counter; inside a tile the rays do not
+// own lanes: work lives in two wave-wide LIFO queues in LDS,
+//     node items (wide node, ray)   and   leaf items (leaf, ray),
+// and every step pops up to 64 items of ONE kind, so node steps and leaf steps both run with (nearly) all lanes
+// busy -- the per-lane state machine above keeps 50-60 % of the lanes busy because a lane holds either node work
+// or triangle work, rarely both.  A node step tests the four child boxes against [tmin, closest hit so far] and
+// appends the hit children to the two queues (ballot + mbcnt compaction); a leaf step tests the leaf's triangles
+// and lowers the ray's closest hit with an LDS atomic min on the float bits.  No ordering, no per-lane stack:
+// the closest committed hit does not depend on the order triangles are met in, and AO rays mostly miss, so
+// near-first ordering would buy little.  The self-hit retry (:193-200) is a second round over the rays that
+// need it.  The node queue cannot overflow: a step pops n items and pushes at most 4n, so n shrinks as the queue
+// fills, down to one item per step = strict depth-first, whose growth is bounded by 3 x tree depth (KQ_GUARD).
+// ---------------------------------------------------------------------------------------------
+#ifndef KQ_NQ
+#define KQ_NQ 1024         // node queue capacity in LDS: 4-byte items, ray << 22 | wide node index
+#endif
+#ifndef KQ_LQ
+#define KQ_LQ 320          // leaf queue capacity in LDS: a node step runs with < 64 leaves queued and adds <= 256
+#endif
+constexpr uint32_t KQ_NODE_BITS = 22;    // the host falls back to k_trace for trees of more than 2^22 wide nodes
+constexpr uint32_t KQ_GUARD = 3u * 32u;   // head-room for strict depth-first growth: 3 deferred children per level, <= 32 levels
+
+VKR_DI uint32_t mbcnt64(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+struct QSliceLayout { uint32_t rays_f4, retry_f4, total_f4; };   // per-wave global scratch, in float4 units
+__host__ __device__ inline QSliceLayout q_slice_layout(int rayCount)
+{
+    QSliceLayout l;
+    l.rays_f4 = (uint32_t)rayCount * 64u * 2u;    // {origin | tMin}, {direction | -} per ray
+    l.retry_f4 = (uint32_t)rayCount * 16u;        // one u32 per ray
+    l.total_f4 = l.rays_f4 + l.retry_f4;
+    return l;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams fp, const uint16_t* depthP,
+                                                      const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
+                                                      int y0, int y1, uint32_t tiles_x, uint32_t n_tiles, float4* rayBuf,
+                                                      uint32_t* tile_counter, unsigned long long* stats)
+{
+    extern __shared__ uint32_t smem[];
+    const int rayCount = fp.rayCount;                                           // :252
+    uint32_t* s_tbest = smem;                                                   // [rayCount * 64] closest hit, float bits
+    uint32_t* s_nq = smem + (uint32_t)rayCount * 64u;                           // node items: ray << 22 | node
+    uint32_t* s_lq = s_nq + KQ_NQ;                                              // leaf items: leaf reference ...
+    uint16_t* s_lqr = (uint16_t*)(s_lq + KQ_LQ);                                // ... and its ray
+
+    const int lane = threadIdx.x;
+    const int W = fp.W, H = fp.H;
+    const Img16 depth{depthP, W, H}, histPrev{histPrevP, W, H};
+    const QSliceLayout lay = q_slice_layout(rayCount);
+    float4* slice = rayBuf + (size_t)blockIdx.x * lay.total_f4;
+    uint32_t* retry_list = (uint32_t*)(slice + lay.rays_f4);
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const char* node_base = (const char*)sc.nodes;
+    const char* tri_base = (const char*)sc.tris;
+    TraceCounters cnt{0, 0, 0, 0};
+    uint32_t nrays = 0;
+
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(tile_counter, 1u);
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+        if (tile >= n_tiles) break;          // every wave reaches this: the counter only grows
+        const int px = (int)(tile % tiles_x) * 8 + (lane & 7);
+        const int py = y0 + (int)(tile / tiles_x) * 8 + (lane >> 3);
+
+        // ------------------------------------------------------------------ phase 1: per pixel
+        PixelCtx pc;
+        pc.valid = false;
+        pc.radius = 0.0f;
+        if (px < W && py < y1) setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);   // :233-235
+        const bool valid = pc.valid;
+        const float radius = pc.radius;
+        const unsigned long long vmask = __ballot(valid);
+        const uint32_t nvalid = (uint32_t)__popcll(vmask);
+        if (nvalid == 0) continue;   // wave-uniform: nothing to trace, nothing to resolve
+        const uint32_t rank = (uint32_t)__popcll(vmask & lt_mask);
+        if (valid) {
+            for (int i = 0; i < rayCount; ++i) {                                    // :403-430
+                V3 rayOrigin, rayDir;
+                float tMinRay;
+                make_ray(pc, rayCount, i, &rayOrigin, &rayDir, &tMinRay);
+                const uint32_t k = (uint32_t)i * nvalid + rank;
+                slice[(size_t)k * 2u] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
+                slice[(size_t)k * 2u + 1u] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
+                s_tbest[k] = f2u(pc.radius);                                        // tMax = radius (:430)
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // ------------------------------------------------------------------ phase 2: queues
+        const uint32_t total = nvalid * (uint32_t)rayCount;
+        uint32_t retry_mask = 0;     // bit i: this pixel's ray i was re-traced
+        uint32_t nretry = 0;
+        for (int round = 0; round < 2; ++round) {
+            const uint32_t set_size = (round == 0) ? total : nretry;
+            if (set_size == 0) break;
+            uint32_t next = 0, nq = 0, lq = 0;      // wave-uniform
+            for (;;) {
+                const bool no_more = (next >= set_size);
+                if (lq >= 64u || (lq > 0u && nq == 0u && no_more)) {
+                    // ---------------- leaf step: queryAoClosestHit's candidate loop (:125-182) for <= 64 leaves
+                    const uint32_t n = lq < 64u ? lq : 64u;
+                    lq -= n;
+                    uint32_t cntT = 0;
+                    uint2 it = make_uint2(0u, 0u);
+                    if ((uint32_t)lane < n) it = make_uint2(s_lq[lq + (uint32_t)lane], (uint32_t)s_lqr[lq + (uint32_t)lane]);
+                    float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 1, 0);
+                    uint32_t first = 0;
+                    float tbest0 = 0.0f;
+                    if ((uint32_t)lane < n) {
+                        a = slice[(size_t)it.y * 2u]; b = slice[(size_t)it.y * 2u + 1u];
+                        const uint32_t x = ~it.x;
+                        first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
+                        tbest0 = u2f(s_tbest[it.y]);
+                    }
+                    V3 ro = V3{a.x, a.y, a.z}, rdir = V3{b.x, b.y, b.z};
+                    float tmin = a.w;
+                    if (round) {                                                    // :193-197
+                        const float adv = gmax(a.w * 2.0f, 2e-4f);
+                        ro = ro + rdir * adv;
+                        tmin = gmax(a.w, 1e-4f);
+                    }
+                    float tbest = tbest0;
+                    for (uint32_t j = 0; j < (uint32_t)VKR_LEAF_MAX; ++j) {
+                        const unsigned long long am = __ballot(j < cntT);
+                        if (am == 0ull) break;
+                        if (j < cntT) {
+                            const float4* tp = (const float4*)(tri_base + (size_t)(first + j) * 48u);
+                            float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
+                            if (STATS) { cnt.tris++; if ((int)(__ffsll((long long)am) - 1) == lane) cnt.wave_tri_iters++; }
+                            V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
+                            V3 pvec = cross3(rdir, e2);
+                            float det = dot3(e1, pvec);
+                            float inv = 1.0f / det;
+                            V3 tvec = ro - v0;
+                            float u = dot3(tvec, pvec) * inv;
+                            V3 qvec = cross3(tvec, e1);
+                            float v = dot3(rdir, qvec) * inv;
+                            float t = dot3(e2, qvec) * inv;
+                            const uint32_t mw = f2u(ta.w);
+                            const uint32_t cls = mw >> 28;                          // candidate filter :142-173
+                            bool hit = (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
+                                       (t > tmin && t < tbest) && (cls != 1u);
+                            if (hit && cls == 2u) hit = alpha_test(sc, mw & 0x0fffffffu, f2u(tb4.w), u, v);
+                            if (hit) tbest = t;
+                        }
+                    }
+                    if (tbest < tbest0) atomicMin(&s_tbest[it.y], f2u(tbest));      // t > tmin >= 0: bits order like floats
+                    continue;
+                }
+                if (nq < 64u && next < set_size) {
+                    // ---------------- inject the next rays at the root
+                    const uint32_t m = (set_size - next) < 64u ? (set_size - next) : 64u;
+                    if ((uint32_t)lane < m) {
+                        const uint32_t ray = round ? retry_list[next + (uint32_t)lane] : next + (uint32_t)lane;
+                        s_nq[nq + (uint32_t)lane] = ray << KQ_NODE_BITS;
+                    }
+                    nq += m; next += m;
+                    if (STATS) { if ((uint32_t)lane < m) nrays++; }
+                }
+                if (nq == 0u) break;
+                // ---------------- node step: pops n, pushes <= 4n node items (and <= 4n leaf items, lq < 64 here)
+                uint32_t n = nq < 64u ? nq : 64u;
+                {
+                    const uint32_t room = (uint32_t)KQ_NQ - KQ_GUARD - (nq < (uint32_t)KQ_NQ - KQ_GUARD ? nq : (uint32_t)KQ_NQ - KQ_GUARD);
+                    const uint32_t fit = room / 3u;
+                    if (n > fit) n = fit ? fit : 1u;
+                }
+                nq -= n;
+                bool h0 = false, h1 = false, h2 = false, h3 = false;
+                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, ray = 0;
+                if ((uint32_t)lane < n) {
+                    const uint32_t item = s_nq[nq + (uint32_t)lane];
+                    ray = item >> KQ_NODE_BITS;
+                    const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
+                    const float4 a = slice[(size_t)ray * 2u], b = slice[(size_t)ray * 2u + 1u];
+                    const float4* np = (const float4*)(node_base + ((size_t)node << 6));
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    const float tb = u2f(s_tbest[ray]) * 1.000001f;   // padded: culling may only err towards extra visits
+                    if (STATS) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.wave_node_iters++; }
+                    V3 ro = V3{a.x, a.y, a.z}, rdir = V3{b.x, b.y, b.z};
+                    float tmin = a.w;
+                    if (round) {
+                        const float adv = gmax(a.w * 2.0f, 2e-4f);
+                        ro = ro + rdir * adv;
+                        tmin = gmax(a.w, 1e-4f);
+                    }
+                    const V3 id = V3{safe_rcp(rdir.x), safe_rcp(rdir.y), safe_rcp(rdir.z)};
+                    // Slab tests straight on the quantised planes (see k_trace): t = fma(q, s*id, (o - ro)*id)
+                    const uint32_t eb = f2u(q0.w);
+                    const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
+                                az = u2f(((eb >> 16) & 0xffu) << 23) * id.z;
+                    const float bx = (q0.x - ro.x) * id.x, by = (q0.y - ro.y) * id.y, bz = (q0.z - ro.z) * id.z;
+                    const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
+                    const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
+                    const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
+                    r0 = f2u(q3.x); r1 = f2u(q3.y); r2 = f2u(q3.z); r3 = f2u(q3.w);
+#define VKR_SLABQ(HC, C)                                                                                            \
+    {                                                                                                               \
+        float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(ubyte_f(nx4, C), ax, bx), fma_(ubyte_f(ny4, C), ay, by)),   \
+                                   __builtin_fmaxf(fma_(ubyte_f(nz4, C), az, bz), tmin));                          \
+        float tf = __builtin_fminf(__builtin_fminf(fma_(ubyte_f(fx4, C), ax, bx), fma_(ubyte_f(fy4, C), ay, by)),   \
+                                   __builtin_fminf(fma_(ubyte_f(fz4, C), az, bz), tb));                            \
+        HC = (tn <= tf);                                                                                            \
+    }
+                    VKR_SLABQ(h0, 0) VKR_SLABQ(h1, 1) VKR_SLABQ(h2, 2) VKR_SLABQ(h3, 3)
+#undef VKR_SLABQ
+                }
+                // append the hit children: internal nodes to the node queue, leaves to the leaf queue
+#define VKR_APPEND(HC, RC)                                                                                          \
+    {                                                                                                               \
+        const bool isl = (int)RC < 0;                                                                               \
+        const unsigned long long mn = __ballot(HC && !isl), ml = __ballot(HC && isl);                               \
+        if (HC) {                                                                                                   \
+            if (isl) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqr[ix] = (uint16_t)ray; }            \
+            else s_nq[nq + mbcnt64(mn)] = (ray << KQ_NODE_BITS) | RC;                                               \
+        }                                                                                                           \
+        nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
+    }
+                VKR_APPEND(h0, r0) VKR_APPEND(h1, r1) VKR_APPEND(h2, r2) VKR_APPEND(h3, r3)
+#undef VKR_APPEND
+            }
+            if (round == 0) {
+                // rays that ended on a self-hit are traced once more from an advanced origin (:193-200)
+                for (int i = 0; i < rayCount; ++i) {
+                    bool need = false;
+                    const uint32_t k = (uint32_t)i * nvalid + rank;
+                    if (valid) {
+                        const float tbv = u2f(s_tbest[k]);
+                        const float tmin0 = slice[(size_t)k * 2u].w;
+                        need = (tbv < radius) && (tbv <= tmin0 * 1.5f);
+                    }
+                    const unsigned long long m = __ballot(need);
+                    if (need) {
+                        retry_list[nretry + mbcnt64(m)] = k;
+                        s_tbest[k] = f2u(radius);
+                        retry_mask |= 1u << i;
+                    }
+                    nretry += (uint32_t)__popcll(m);
+                }
+                if (nretry) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ phase 3: per pixel resolve + temporal
+        if (valid) {
+            float visibility = 0.0f;
+            uint32_t mask = 0;
+            for (int i = 0; i < rayCount; ++i) {                                    // :431 in ray order
+                const uint32_t k = (uint32_t)i * nvalid + rank;
+                const float tbv = u2f(s_tbest[k]);
+                const float tmin0 = slice[(size_t)k * 2u].w;
+                const float tmax = radius;
+                float vis = 1.0f;
+                if (tbv < tmax) {                                                   // a hit was committed
+                    const bool retried = (retry_mask >> i) & 1u;
+                    const float adv = gmax(tmin0 * 2.0f, 2e-4f);
+                    const float t = retried ? (tbv + adv) : tbv;
+                    if (!(t <= tmin0 * 1.5f)) {                                     // :205-212
+                        float x = gclamp((t - tmin0) / gmax(tmax - tmin0, 1e-3f), 0.0f, 1.0f);
+                        vis = pow3(x);
+                        mask |= 1u << i;
+                    }
+                }
+                visibility += vis;
+            }
+            // the pixel context is rebuilt rather than kept in registers across the queue loop (it is ~25 VGPRs, and
+            // the loop's occupancy matters more than ~500 instructions per pixel): same inputs, same values
+            PixelCtx pc2;
+            setup_pixel(fp, depth, histCurr, hitMask, px, py, pc2);
+            resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc2, visibility, mask);
+        }
+    }
+    if (STATS) {
+        atomicAdd(&stats[0], (unsigned long long)nrays);
+        atomicAdd(&stats[1], (unsigned long long)cnt.nodes);
+        atomicAdd(&stats[2], (unsigned long long)cnt.tris);
+        atomicAdd(&stats[3], (unsigned long long)cnt.wave_node_iters);
+        atomicAdd(&stats[4], (unsigned long long)cnt.wave_tri_iters);
+    }
+}
+
 hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,
                              uint16_t* hist_curr, uint32_t* hit_mask, int y0, int y1, hipStream_t st)
 {
     if (y1 <= y0) return hipSuccess;
     uint32_t tiles_x = ((uint32_t)fp.W + 7u) / 8u, tiles_y = ((uint32_t)(y1 - y0) + 7u) / 8u;
     uint32_t n_tiles = tiles_x * tiles_y;
+    SceneDev sc = scene_dev(c);
+    hipError_t e;
+    if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
+        // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
+        const size_t lds = (size_t)fp.rayCount * 64u * 4u + (size_t)KQ_NQ * 4u + (size_t)KQ_LQ * 6u;
+        int per_cu = 0;
+        if (c->stats_enabled) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<true>, K1_BLOCK, lds);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false>, K1_BLOCK, lds);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
+        if (blocks > n_tiles) blocks = n_tiles;
+        const size_t need = (size_t)blocks * q_slice_layout(fp.rayCount).total_f4;
+        if (c->d_raybuf.n < need) {
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+            if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
+        }
+        if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(1)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
+        if (c->stats_enabled)
+            k_trace_q<true><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
+                                                           n_tiles, c->d_raybuf.p, c->d_tile_counter.p, c->d_stats.p);
+        else
+            k_trace_q<false><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
+                                                            n_tiles, c->d_raybuf.p, c->d_tile_counter.p, nullptr);
+        return hipGetLastError();
+    }
     // ray buffer: one slice per wave of the launch, sized for the current rays/px (grow-only, so steady-state
     // frames allocate nothing)
     size_t need = (size_t)n_tiles * ((size_t)fp.rayCount * 64u * 2u + (size_t)fp.rayCount * 16u);
     if (c->d_raybuf.n < need) {
-        hipError_t e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
         if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
     }
-    SceneDev sc = scene_dev(c);
     if (c->stats_enabled)
         k_trace<true><<<n_tiles, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
                                                    c->d_raybuf.p, c->d_stats.p);

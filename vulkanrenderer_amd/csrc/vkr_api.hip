@@ -113,7 +113,10 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     vkr_ctx* c = new vkr_ctx();
     c->device = desc->device;
     c->W = desc->width;
+    // experiment switches (development only; defaults are the shipped configuration)
     if (const char* e = getenv("VKR_MORTON_EMC")) c->morton_emc = (e[0] == '1');
+    if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
+    (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     c->H = desc->height;
     auto bail = [&](int code, const char* what, hipError_t err) {
         fail(nullptr, code, "vkr_create: %s: %s", what, hipGetErrorString(err));
