@@ -558,6 +558,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #ifndef KQ_LQ
 #define KQ_LQ 320          // leaf queue capacity in LDS: a node step runs with < 64 leaves queued and adds <= 256
 #endif
+constexpr int KQ_AQ = 128;               // alpha-test queue: drained whenever it holds a full wave of candidates
 constexpr uint32_t KQ_NODE_BITS = 22;    // the host falls back to k_trace for trees of more than 2^22 wide nodes
 constexpr uint32_t KQ_GUARD = 3u * 32u;   // head-room for strict depth-first growth: 3 deferred children per level, <= 32 levels
 
@@ -576,6 +577,24 @@ __host__ __device__ inline QSliceLayout q_slice_layout(int rayCount)
     return l;
 }
 
+// Moeller-Trumbore exactly as in k_trace / traverse<>() (operation order is part of the numeric contract): no culling,
+// t strictly inside (tmin, tbest).
+VKR_DI bool tri_hit(V3 ro, V3 rdir, float4 ta, float4 tb4, float4 tc, float tmin, float tbest, float* uo, float* vo,
+                    float* to)
+{
+    V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
+    V3 pvec = cross3(rdir, e2);
+    float det = dot3(e1, pvec);
+    float inv = 1.0f / det;
+    V3 tvec = ro - v0;
+    float u = dot3(tvec, pvec) * inv;
+    V3 qvec = cross3(tvec, e1);
+    float v = dot3(rdir, qvec) * inv;
+    float t = dot3(e2, qvec) * inv;
+    *uo = u; *vo = v; *to = t;
+    return (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) && (t > tmin && t < tbest);
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams fp, const uint16_t* depthP,
                                                       const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
@@ -588,6 +607,8 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
     uint32_t* s_nq = smem + (uint32_t)rayCount * 64u;                           // node items: ray << 22 | node
     uint32_t* s_lq = s_nq + KQ_NQ;                                              // leaf items: leaf reference ...
     uint16_t* s_lqr = (uint16_t*)(s_lq + KQ_LQ);                                // ... and its ray
+    uint32_t* s_aq = (uint32_t*)(s_lqr + KQ_LQ);                                // MASK candidates: triangle index ...
+    uint16_t* s_aqr = (uint16_t*)(s_aq + KQ_AQ);                                // ... and its ray
 
     const int lane = threadIdx.x;
     const int W = fp.W, H = fp.H;
@@ -641,9 +662,31 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
         for (int round = 0; round < 2; ++round) {
             const uint32_t set_size = (round == 0) ? total : nretry;
             if (set_size == 0) break;
-            uint32_t next = 0, nq = 0, lq = 0;      // wave-uniform
+            uint32_t next = 0, nq = 0, lq = 0, aq = 0;      // wave-uniform
+            // ---------------- alpha step: MASK candidates (:163-173), n items from s_aq[base..]
+            auto alpha_step = [&](uint32_t n, uint32_t base) {
+                if ((uint32_t)lane < n) {
+                    const uint32_t tri = s_aq[base + (uint32_t)lane], ray = (uint32_t)s_aqr[base + (uint32_t)lane];
+                    const float4 a = slice[(size_t)ray * 2u], b = slice[(size_t)ray * 2u + 1u];
+                    const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
+                    const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
+                    V3 ro = V3{a.x, a.y, a.z}, rdir = V3{b.x, b.y, b.z};
+                    float tmin = a.w;
+                    if (round) {
+                        const float adv = gmax(a.w * 2.0f, 2e-4f);
+                        ro = ro + rdir * adv;
+                        tmin = gmax(a.w, 1e-4f);
+                    }
+                    float u, v, t;
+                    const float tbest = u2f(s_tbest[ray]);
+                    if (tri_hit(ro, rdir, ta, tb4, tc, tmin, tbest, &u, &v, &t) &&
+                        alpha_test(sc, f2u(ta.w) & 0x0fffffffu, f2u(tb4.w), u, v))
+                        atomicMin(&s_tbest[ray], f2u(t));
+                }
+            };
             for (;;) {
                 const bool no_more = (next >= set_size);
+                if (aq > 0u && lq < 64u && nq == 0u && no_more) { alpha_step(aq, 0u); aq = 0u; continue; }
                 if (lq >= 64u || (lq > 0u && nq == 0u && no_more)) {
                     // ---------------- leaf step: queryAoClosestHit's candidate loop (:125-182) for <= 64 leaves
                     const uint32_t n = lq < 64u ? lq : 64u;
@@ -671,25 +714,24 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
                     for (uint32_t j = 0; j < (uint32_t)VKR_LEAF_MAX; ++j) {
                         const unsigned long long am = __ballot(j < cntT);
                         if (am == 0ull) break;
+                        bool cand = false;   // MASK candidate: geometric hit that still needs the alpha test
                         if (j < cntT) {
                             const float4* tp = (const float4*)(tri_base + (size_t)(first + j) * 48u);
                             float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
                             if (STATS) { cnt.tris++; if ((int)(__ffsll((long long)am) - 1) == lane) cnt.wave_tri_iters++; }
-                            V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
-                            V3 pvec = cross3(rdir, e2);
-                            float det = dot3(e1, pvec);
-                            float inv = 1.0f / det;
-                            V3 tvec = ro - v0;
-                            float u = dot3(tvec, pvec) * inv;
-                            V3 qvec = cross3(tvec, e1);
-                            float v = dot3(rdir, qvec) * inv;
-                            float t = dot3(e2, qvec) * inv;
-                            const uint32_t mw = f2u(ta.w);
-                            const uint32_t cls = mw >> 28;                          // candidate filter :142-173
-                            bool hit = (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
-                                       (t > tmin && t < tbest) && (cls != 1u);
-                            if (hit && cls == 2u) hit = alpha_test(sc, mw & 0x0fffffffu, f2u(tb4.w), u, v);
-                            if (hit) tbest = t;
+                            float u, v, t;
+                            const bool geo = tri_hit(ro, rdir, ta, tb4, tc, tmin, tbest, &u, &v, &t);
+                            const uint32_t cls = f2u(ta.w) >> 28;                   // candidate filter :142-173
+                            if (geo && cls == 0u) tbest = t;
+                            cand = geo && cls == 2u;
+                        }
+                        // alpha tests are not run here at one or two lanes' width: candidates queue up and are tested
+                        // a wave at a time (accepting a hit later only delays pruning; the minimum is the same)
+                        const unsigned long long cm = __ballot(cand);
+                        if (cm != 0ull) {
+                            if (cand) { const uint32_t ix = aq + mbcnt64(cm); s_aq[ix] = first + j; s_aqr[ix] = (uint16_t)it.y; }
+                            aq += (uint32_t)__popcll(cm);
+                            if (aq >= 64u) { aq -= 64u; alpha_step(64u, aq); }
                         }
                     }
                     if (tbest < tbest0) atomicMin(&s_tbest[it.y], f2u(tbest));      // t > tmin >= 0: bits order like floats
@@ -840,7 +882,7 @@ hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* 
     hipError_t e;
     if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
         // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
-        const size_t lds = (size_t)fp.rayCount * 64u * 4u + (size_t)KQ_NQ * 4u + (size_t)KQ_LQ * 6u;
+        const size_t lds = (size_t)fp.rayCount * 64u * 4u + (size_t)KQ_NQ * 4u + (size_t)KQ_LQ * 6u + (size_t)KQ_AQ * 6u;
         int per_cu = 0;
         if (c->stats_enabled) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<true>, K1_BLOCK, lds);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false>, K1_BLOCK, lds);
