@@ -567,11 +567,27 @@ VKR_DI uint32_t mbcnt64(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// wave64 inclusive prefix sum (DPP: four shifted adds inside each row of 16, then the two row broadcasts)
+VKR_DI uint32_t wave_incl_scan(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)v;
+}
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+VKR_DI f2v pk_fma(f2v a, float b, float c) { return __builtin_elementwise_fma(a, f2v{b, b}, f2v{c, c}); }   // v_pk_fma_f32
+
 struct QSliceLayout { uint32_t rays_f4, retry_f4, total_f4; };   // per-wave global scratch, in float4 units
 __host__ __device__ inline QSliceLayout q_slice_layout(int rayCount)
 {
     QSliceLayout l;
-    l.rays_f4 = (uint32_t)rayCount * 64u * 2u;    // {origin | tMin}, {direction | -} per ray
+    l.rays_f4 = (uint32_t)rayCount * 64u * 3u;    // {origin | tMin}, {direction | -}, {1/direction | -} per ray
     l.retry_f4 = (uint32_t)rayCount * 16u;        // one u32 per ray
     l.total_f4 = l.rays_f4 + l.retry_f4;
     return l;
@@ -647,8 +663,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
                 float tMinRay;
                 make_ray(pc, rayCount, i, &rayOrigin, &rayDir, &tMinRay);
                 const uint32_t k = (uint32_t)i * nvalid + rank;
-                slice[(size_t)k * 2u] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
-                slice[(size_t)k * 2u + 1u] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
+                slice[(size_t)k * 3u] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
+                slice[(size_t)k * 3u + 1u] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
+                slice[(size_t)k * 3u + 2u] = make_float4(safe_rcp(rayDir.x), safe_rcp(rayDir.y), safe_rcp(rayDir.z), 0.0f);
                 s_tbest[k] = f2u(pc.radius);                                        // tMax = radius (:430)
             }
         }
@@ -667,7 +684,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
             auto alpha_step = [&](uint32_t n, uint32_t base) {
                 if ((uint32_t)lane < n) {
                     const uint32_t tri = s_aq[base + (uint32_t)lane], ray = (uint32_t)s_aqr[base + (uint32_t)lane];
-                    const float4 a = slice[(size_t)ray * 2u], b = slice[(size_t)ray * 2u + 1u];
+                    const float4 a = slice[(size_t)ray * 3u], b = slice[(size_t)ray * 3u + 1u];
                     const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
                     const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
                     V3 ro = V3{a.x, a.y, a.z}, rdir = V3{b.x, b.y, b.z};
@@ -698,7 +715,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
                     uint32_t first = 0;
                     float tbest0 = 0.0f;
                     if ((uint32_t)lane < n) {
-                        a = slice[(size_t)it.y * 2u]; b = slice[(size_t)it.y * 2u + 1u];
+                        a = slice[(size_t)it.y * 3u]; b = slice[(size_t)it.y * 3u + 1u];
                         const uint32_t x = ~it.x;
                         first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
                         tbest0 = u2f(s_tbest[it.y]);
@@ -742,7 +759,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
                     const uint32_t m = (set_size - next) < 64u ? (set_size - next) : 64u;
                     if ((uint32_t)lane < m) {
                         const uint32_t ray = round ? retry_list[next + (uint32_t)lane] : next + (uint32_t)lane;
-                        s_nq[nq + (uint32_t)lane] = ray << KQ_NODE_BITS;
+                        s_nq[nq + (uint32_t)lane] = ray << KQ_NODE_BITS;   // root = node 0
                     }
                     nq += m; next += m;
                     if (STATS) { if ((uint32_t)lane < m) nrays++; }
@@ -756,25 +773,26 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
                     if (n > fit) n = fit ? fit : 1u;
                 }
                 nq -= n;
-                bool h0 = false, h1 = false, h2 = false, h3 = false;
+                uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
                 uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, ray = 0;
                 if ((uint32_t)lane < n) {
                     const uint32_t item = s_nq[nq + (uint32_t)lane];
                     ray = item >> KQ_NODE_BITS;
                     const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
-                    const float4 a = slice[(size_t)ray * 2u], b = slice[(size_t)ray * 2u + 1u];
+                    const float4 a = slice[(size_t)ray * 3u], ir = slice[(size_t)ray * 3u + 2u];
                     const float4* np = (const float4*)(node_base + ((size_t)node << 6));
                     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     const float tb = u2f(s_tbest[ray]) * 1.000001f;   // padded: culling may only err towards extra visits
                     if (STATS) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.wave_node_iters++; }
-                    V3 ro = V3{a.x, a.y, a.z}, rdir = V3{b.x, b.y, b.z};
+                    V3 ro = V3{a.x, a.y, a.z};
                     float tmin = a.w;
                     if (round) {
+                        const float4 b = slice[(size_t)ray * 3u + 1u];
                         const float adv = gmax(a.w * 2.0f, 2e-4f);
-                        ro = ro + rdir * adv;
+                        ro = ro + V3{b.x, b.y, b.z} * adv;
                         tmin = gmax(a.w, 1e-4f);
                     }
-                    const V3 id = V3{safe_rcp(rdir.x), safe_rcp(rdir.y), safe_rcp(rdir.z)};
+                    const V3 id = V3{ir.x, ir.y, ir.z};
                     // Slab tests straight on the quantised planes (see k_trace): t = fma(q, s*id, (o - ro)*id)
                     const uint32_t eb = f2u(q0.w);
                     const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
@@ -784,18 +802,28 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
                     const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
                     const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
                     r0 = f2u(q3.x); r1 = f2u(q3.y); r2 = f2u(q3.z); r3 = f2u(q3.w);
-#define VKR_SLABQ(HC, C)                                                                                            \
+                    // two children per packed fma (v_pk_fma_f32 rounds each half like the scalar fma)
+#define VKR_PLANES(W, A, B, P01, P23)                                                                               \
+    const f2v P01 = pk_fma(f2v{ubyte_f(W, 0), ubyte_f(W, 1)}, A, B), P23 = pk_fma(f2v{ubyte_f(W, 2), ubyte_f(W, 3)}, A, B);
+                    VKR_PLANES(nx4, ax, bx, nx01, nx23) VKR_PLANES(ny4, ay, by, ny01, ny23) VKR_PLANES(nz4, az, bz, nz01, nz23)
+                    VKR_PLANES(fx4, ax, bx, fx01, fx23) VKR_PLANES(fy4, ay, by, fy01, fy23) VKR_PLANES(fz4, az, bz, fz01, fz23)
+#undef VKR_PLANES
+#define VKR_SLABQ(HC, NX, NY, NZ, FX, FY, FZ)                                                                       \
     {                                                                                                               \
-        float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(ubyte_f(nx4, C), ax, bx), fma_(ubyte_f(ny4, C), ay, by)),   \
-                                   __builtin_fmaxf(fma_(ubyte_f(nz4, C), az, bz), tmin));                          \
-        float tf = __builtin_fminf(__builtin_fminf(fma_(ubyte_f(fx4, C), ax, bx), fma_(ubyte_f(fy4, C), ay, by)),   \
-                                   __builtin_fminf(fma_(ubyte_f(fz4, C), az, bz), tb));                            \
-        HC = (tn <= tf);                                                                                            \
+        float tn = __builtin_fmaxf(__builtin_fmaxf(NX, NY), __builtin_fmaxf(NZ, tmin));                             \
+        float tf = __builtin_fminf(__builtin_fminf(FX, FY), __builtin_fminf(FZ, tb));                               \
+        HC = (tn <= tf) ? f2u(tn) : 0xffffffffu;                                                                    \
     }
-                    VKR_SLABQ(h0, 0) VKR_SLABQ(h1, 1) VKR_SLABQ(h2, 2) VKR_SLABQ(h3, 3)
+                    VKR_SLABQ(k0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)
+                    VKR_SLABQ(k1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)
+                    VKR_SLABQ(k2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)
+                    VKR_SLABQ(k3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
 #undef VKR_SLABQ
                 }
-                // append the hit children: internal nodes to the node queue, leaves to the leaf queue
+                const bool h0 = k0 != 0xffffffffu, h1 = k1 != 0xffffffffu, h2 = k2 != 0xffffffffu, h3 = k3 != 0xffffffffu;
+                // append the hit children: internal nodes to the node queue, leaves to the leaf queue, slot by slot
+                // (measured: sorting them near-to-far first saves 1 % of the visits and costs more than that; one
+                // lane-major prefix sum instead of per-slot ballots makes a ray's siblings pop together and costs 9 %)
 #define VKR_APPEND(HC, RC)                                                                                          \
     {                                                                                                               \
         const bool isl = (int)RC < 0;                                                                               \
@@ -816,7 +844,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
                     const uint32_t k = (uint32_t)i * nvalid + rank;
                     if (valid) {
                         const float tbv = u2f(s_tbest[k]);
-                        const float tmin0 = slice[(size_t)k * 2u].w;
+                        const float tmin0 = slice[(size_t)k * 3u].w;
                         need = (tbv < radius) && (tbv <= tmin0 * 1.5f);
                     }
                     const unsigned long long m = __ballot(need);
@@ -841,7 +869,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
             for (int i = 0; i < rayCount; ++i) {                                    // :431 in ray order
                 const uint32_t k = (uint32_t)i * nvalid + rank;
                 const float tbv = u2f(s_tbest[k]);
-                const float tmin0 = slice[(size_t)k * 2u].w;
+                const float tmin0 = slice[(size_t)k * 3u].w;
                 const float tmax = radius;
                 float vis = 1.0f;
                 if (tbv < tmax) {                                                   // a hit was committed
