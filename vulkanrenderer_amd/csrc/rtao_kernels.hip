@@ -102,14 +102,6 @@ VKR_DI bool computePrevUv(const float* prevViewProj, V3 worldPos, V2* prevUv)  /
 // ---------------------------------------------------------------------------------------------
 constexpr int CUR_DONE = (int)0x80000000;
 
-// 1/x for slab tests: approximate reciprocal, magnitude capped so that 0 * inf never appears (a ray parallel to a
-// slab then sees +-1e18-scaled distances, which order exactly like the infinite ones)
-VKR_DI float safe_rcp(float x)
-{
-    float r = __builtin_amdgcn_rcpf(x);
-    float a = __builtin_fminf(__builtin_fabsf(r), 1.0e18f);
-    return __builtin_copysignf(a, x);
-}
 constexpr int K1_BLOCK = 64;
 
 VKR_DI uint32_t ray_slice_float4s(int rayCount) { return (uint32_t)rayCount * 64u * 2u + (uint32_t)rayCount * 16u; }
@@ -552,37 +544,6 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 // need it.  The node queue cannot overflow: a step pops n items and pushes at most 4n, so n shrinks as the queue
 // fills, down to one item per step = strict depth-first, whose growth is bounded by 3 x tree depth (KQ_GUARD).
 // ---------------------------------------------------------------------------------------------
-#ifndef KQ_NQ
-#define KQ_NQ 1024         // node queue capacity in LDS: 4-byte items, ray << 22 | wide node index
-#endif
-#ifndef KQ_LQ
-#define KQ_LQ 320          // leaf queue capacity in LDS: a node step runs with < 64 leaves queued and adds <= 256
-#endif
-constexpr int KQ_AQ = 128;               // alpha-test queue: drained whenever it holds a full wave of candidates
-constexpr uint32_t KQ_NODE_BITS = 22;    // the host falls back to k_trace for trees of more than 2^22 wide nodes
-constexpr uint32_t KQ_GUARD = 3u * 32u;   // head-room for strict depth-first growth: 3 deferred children per level, <= 32 levels
-
-VKR_DI uint32_t mbcnt64(unsigned long long m)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// wave64 inclusive prefix sum (DPP: four shifted adds inside each row of 16, then the two row broadcasts)
-VKR_DI uint32_t wave_incl_scan(uint32_t x)
-{
-    int v = (int)x;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-    return (uint32_t)v;
-}
-
-typedef float f2v __attribute__((ext_vector_type(2)));
-VKR_DI f2v pk_fma(f2v a, float b, float c) { return __builtin_elementwise_fma(a, f2v{b, b}, f2v{c, c}); }   // v_pk_fma_f32
-
 struct QSliceLayout { uint32_t rays_f4, retry_f4, total_f4; };   // per-wave global scratch, in float4 units
 __host__ __device__ inline QSliceLayout q_slice_layout(int rayCount)
 {
@@ -591,24 +552,6 @@ __host__ __device__ inline QSliceLayout q_slice_layout(int rayCount)
     l.retry_f4 = (uint32_t)rayCount * 16u;        // one u32 per ray
     l.total_f4 = l.rays_f4 + l.retry_f4;
     return l;
-}
-
-// Moeller-Trumbore exactly as in k_trace / traverse<>() (operation order is part of the numeric contract): no culling,
-// t strictly inside (tmin, tbest).
-VKR_DI bool tri_hit(V3 ro, V3 rdir, float4 ta, float4 tb4, float4 tc, float tmin, float tbest, float* uo, float* vo,
-                    float* to)
-{
-    V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
-    V3 pvec = cross3(rdir, e2);
-    float det = dot3(e1, pvec);
-    float inv = 1.0f / det;
-    V3 tvec = ro - v0;
-    float u = dot3(tvec, pvec) * inv;
-    V3 qvec = cross3(tvec, e1);
-    float v = dot3(rdir, qvec) * inv;
-    float t = dot3(e2, qvec) * inv;
-    *uo = u; *vo = v; *to = t;
-    return (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) && (t > tmin && t < tbest);
 }
 
 template <bool STATS>

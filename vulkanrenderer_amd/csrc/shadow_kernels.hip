@@ -131,10 +131,309 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer(SceneDev sc, FrameP
     if (validOut) validOut[o] = valid ? 1 : 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K4/K5, streaming form: the any-hit counterpart of k_trace_q (rtao_kernels.hip).  Persistent waves pull chunks
+// of pixels; the chunk's rays live in two wave-wide LIFO queues in LDS (node items, leaf items) and every step pops
+// up to 64 items of one kind.  A ray that has found an occluder (any triangle: gl_RayFlagsOpaqueEXT |
+// TerminateOnFirstHit, pbr.frag:205-207) is flagged in an LDS bit set and its remaining items are dropped as they
+// are popped.  Results are order-independent: "some triangle is hit inside (tMin, tMax)".
+//   MODE 0 (sun)  : chunk = 64 pixels x n sample directions; the n directions are frame constants (pbr.frag:239-256
+//                   has no per-pixel rotation), so a ray is (pixel origin in LDS, direction index)
+//   MODE 1 (point): chunk = 256 pixels x 1 ray; per-ray records {origin|tMin, dir|tMax, 1/dir} in a global slice
+// ---------------------------------------------------------------------------------------------
+constexpr int SQ_POINT_PIX = 256;
+
+struct ShadowArgs {
+    const float* wp; const float* ng; const uint8_t* valid; uint32_t count;
+    V3 L;                 // sun: direction to the light (caller-normalised input, normalised again like the shader)
+    float sunRadius, sampleCountF;
+    V3 lightPos;          // point
+    float* out;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uint32_t n_chunks, float4* rayBuf,
+                                                 uint32_t* chunk_counter)
+{
+    __shared__ uint32_t s_nq[KQ_NQ];
+    __shared__ uint32_t s_lq[KQ_LQ];
+    __shared__ uint16_t s_lqr[KQ_LQ];
+    __shared__ uint32_t s_occ[32];          // one bit per ray of the chunk (<= 1024)
+    __shared__ float4 s_org[64];            // sun: ray origin per pixel
+    __shared__ float4 s_dir[16], s_idr[16]; // sun: sample directions and their reciprocals
+
+    const int lane = threadIdx.x;
+    const char* node_base = (const char*)sc.nodes;
+    const char* tri_base = (const char*)sc.tris;
+    float4* slice = rayBuf + (size_t)blockIdx.x * (SQ_POINT_PIX * 3);   // point mode only
+
+    // ---- sun: frame constants (pbr.frag:219-229, 239-256)
+    int n_samples = 1;
+    bool hard = true, no_light = false;
+    if (MODE == 0) {
+        const V3 L = sa.L;
+        no_light = dot3(L, L) < 1e-8f;                                           // :219-222
+        const V3 rayDir = normalize3(L);                                         // :223
+        n_samples = iclamp((int)(sa.sampleCountF + 0.5f), 1, 16);                // :228-229
+        hard = (sa.sunRadius <= 0.0f || n_samples <= 1);                         // :232
+        if (hard) n_samples = 1;
+        if (lane < n_samples) {
+            V3 d = rayDir;
+            if (!hard) {
+                V3 up = (__builtin_fabsf(rayDir.y) < 0.999f) ? v3(0, 1, 0) : v3(0, 0, 1);   // :239
+                V3 T = normalize3(cross3(up, rayDir));                            // :240
+                V3 B = cross3(rayDir, T);                                         // :241
+                float ux = kPoisson[lane][0], uy = kPoisson[lane][1];
+                V3 offset = V3{sa.sunRadius * (ux * T.x + uy * B.x), sa.sunRadius * (ux * T.y + uy * B.y),
+                               sa.sunRadius * (ux * T.z + uy * B.z)};
+                d = normalize3(rayDir + offset);                                  // :255
+            }
+            s_dir[lane] = make_float4(d.x, d.y, d.z, 0.0f);
+            s_idr[lane] = make_float4(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z), 0.0f);
+        }
+    }
+
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(chunk_counter, 1u);
+        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+        if (chunk >= n_chunks) break;        // every wave reaches this: the counter only grows
+
+        // ------------------------------------------------------------------ phase 1: rays of the chunk
+        if (lane < 32) s_occ[lane] = 0u;
+        uint32_t n_rays = 0;                 // rays of this chunk (wave-uniform)
+        bool pvalid = false;                 // sun: this lane's pixel casts rays
+        uint32_t pix0 = 0;
+        if (MODE == 0) {
+            pix0 = chunk * 64u;
+            const uint32_t i = pix0 + (uint32_t)lane;
+            if (i < sa.count) {
+                if ((sa.valid && !sa.valid[i]) || no_light) sa.out[i] = 1.0f;
+                else {
+                    V3 worldPos = V3{sa.wp[3 * (size_t)i], sa.wp[3 * (size_t)i + 1], sa.wp[3 * (size_t)i + 2]};
+                    V3 geomNormal = V3{sa.ng[3 * (size_t)i], sa.ng[3 * (size_t)i + 1], sa.ng[3 * (size_t)i + 2]};
+                    V3 rayOrigin = worldPos + geomNormal * 0.002f;                // :224-225
+                    s_org[lane] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
+                    pvalid = true;
+                }
+            }
+            n_rays = 64u * (uint32_t)n_samples;          // ray r = sample * 64 + pixel lane; invalid pixels never inject
+        } else {
+            pix0 = chunk * (uint32_t)SQ_POINT_PIX;
+            for (int j = 0; j < SQ_POINT_PIX / 64; ++j) {
+                const uint32_t r = (uint32_t)j * 64u + (uint32_t)lane;
+                const uint32_t i = pix0 + r;
+                float4 a = make_float4(0, 0, 0, -1.0f);   // tMin < 0 marks "no ray"
+                float4 b = make_float4(0, 0, 1, 0), c = make_float4(0, 0, 0, 0);
+                if (i < sa.count) {
+                    if (sa.valid && !sa.valid[i]) sa.out[i] = 1.0f;
+                    else {
+                        V3 worldPos = V3{sa.wp[3 * (size_t)i], sa.wp[3 * (size_t)i + 1], sa.wp[3 * (size_t)i + 2]};
+                        V3 geomNormal = V3{sa.ng[3 * (size_t)i], sa.ng[3 * (size_t)i + 1], sa.ng[3 * (size_t)i + 2]};
+                        V3 toLight = sa.lightPos - worldPos;                      // :171
+                        float lightDistance = length3(toLight);                   // :172
+                        if (lightDistance <= 0.0001f) sa.out[i] = 1.0f;           // :173-175
+                        else {
+                            V3 rayDir = V3{toLight.x / lightDistance, toLight.y / lightDistance, toLight.z / lightDistance};  // :177
+                            float bias = gmax(0.002f, 0.0005f * lightDistance);   // :178
+                            V3 rayOrigin = worldPos + geomNormal * bias;          // :179
+                            float tMin = 0.001f;                                  // :180
+                            float tMax = gmax(lightDistance - bias, tMin);        // :181
+                            a = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMin);
+                            b = make_float4(rayDir.x, rayDir.y, rayDir.z, tMax);
+                            c = make_float4(safe_rcp(rayDir.x), safe_rcp(rayDir.y), safe_rcp(rayDir.z), 0.0f);
+                        }
+                    }
+                }
+                slice[(size_t)r * 3u] = a; slice[(size_t)r * 3u + 1u] = b; slice[(size_t)r * 3u + 2u] = c;
+            }
+            n_rays = (uint32_t)SQ_POINT_PIX;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        const unsigned long long pvmask = __ballot(pvalid);
+
+        // ------------------------------------------------------------------ phase 2: queues
+        if (sc.tri_count != 0u) {
+            uint32_t next = 0, nq = 0, lq = 0;      // wave-uniform
+            for (;;) {
+                const bool no_more = (next >= n_rays);
+                if (lq >= 64u || (lq > 0u && nq == 0u && no_more)) {
+                    // ---------------- leaf step: any triangle inside (tMin, tMax) occludes (pbr.frag:199-215)
+                    const uint32_t n = lq < 64u ? lq : 64u;
+                    lq -= n;
+                    uint32_t cntT = 0, first = 0, ray = 0;
+                    V3 ro = v3(0, 0, 0), rdir = v3(0, 0, 1);
+                    float tmin = 0.0f, tmax = 0.0f;
+                    if ((uint32_t)lane < n) {
+                        const uint32_t ref = s_lq[lq + (uint32_t)lane];
+                        ray = (uint32_t)s_lqr[lq + (uint32_t)lane];
+                        if (!((s_occ[ray >> 5] >> (ray & 31u)) & 1u)) {
+                            const uint32_t x = ~ref;
+                            first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
+                            if (MODE == 0) {
+                                const float4 o = s_org[ray & 63u], d = s_dir[ray >> 6];
+                                ro = V3{o.x, o.y, o.z}; rdir = V3{d.x, d.y, d.z}; tmin = 0.001f; tmax = 500.0f;   // :203-204
+                            } else {
+                                const float4 a = slice[(size_t)ray * 3u], b = slice[(size_t)ray * 3u + 1u];
+                                ro = V3{a.x, a.y, a.z}; rdir = V3{b.x, b.y, b.z}; tmin = a.w; tmax = b.w;
+                            }
+                        }
+                    }
+                    bool occluded = false;
+                    for (uint32_t j = 0; j < (uint32_t)VKR_LEAF_MAX; ++j) {
+                        if (__ballot(j < cntT && !occluded) == 0ull) break;
+                        if (j < cntT && !occluded) {
+                            const float4* tp = (const float4*)(tri_base + (size_t)(first + j) * 48u);
+                            float u, v, t;
+                            occluded = tri_hit(ro, rdir, tp[0], tp[1], tp[2], tmin, tmax, &u, &v, &t);
+                        }
+                    }
+                    if (occluded) atomicOr(&s_occ[ray >> 5], 1u << (ray & 31u));
+                    continue;
+                }
+                if (nq < 64u && next < n_rays) {
+                    // ---------------- inject the next rays at the root
+                    const uint32_t r = next + (uint32_t)lane;
+                    bool inj = false;
+                    if (r < n_rays) {
+                        if (MODE == 0) inj = (pvmask >> (r & 63u)) & 1ull;
+                        else inj = slice[(size_t)r * 3u].w >= 0.0f;
+                    }
+                    const unsigned long long im = __ballot(inj);
+                    if (inj) s_nq[nq + mbcnt64(im)] = r << KQ_NODE_BITS;
+                    nq += (uint32_t)__popcll(im);
+                    next += 64u;
+                    continue;
+                }
+                if (nq == 0u) { if (no_more) break; else continue; }
+                // ---------------- node step: pops n, pushes <= 4n node items (and <= 4n leaf items, lq < 64 here)
+                uint32_t n = nq < 64u ? nq : 64u;
+                {
+                    const uint32_t room = (uint32_t)KQ_NQ - KQ_GUARD - (nq < (uint32_t)KQ_NQ - KQ_GUARD ? nq : (uint32_t)KQ_NQ - KQ_GUARD);
+                    const uint32_t fit = room / 3u;
+                    if (n > fit) n = fit ? fit : 1u;
+                }
+                nq -= n;
+                bool h0 = false, h1 = false, h2 = false, h3 = false;
+                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, ray = 0;
+                if ((uint32_t)lane < n) {
+                    const uint32_t item = s_nq[nq + (uint32_t)lane];
+                    ray = item >> KQ_NODE_BITS;
+                    if (!((s_occ[ray >> 5] >> (ray & 31u)) & 1u)) {
+                        const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
+                        const float4* np = (const float4*)(node_base + ((size_t)node << 6));
+                        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                        V3 ro, id;
+                        float tmin, tb;
+                        if (MODE == 0) {
+                            const float4 o = s_org[ray & 63u], d = s_idr[ray >> 6];
+                            ro = V3{o.x, o.y, o.z}; id = V3{d.x, d.y, d.z}; tmin = 0.001f; tb = 500.0f * 1.000001f;
+                        } else {
+                            const float4 a = slice[(size_t)ray * 3u], b = slice[(size_t)ray * 3u + 1u], c = slice[(size_t)ray * 3u + 2u];
+                            ro = V3{a.x, a.y, a.z}; id = V3{c.x, c.y, c.z}; tmin = a.w; tb = b.w * 1.000001f;
+                        }
+                        // Slab tests on the quantised planes as in k_trace_q; these rays are long, so the interval gets
+                        // the relative padding of box_key() on top (rounding may only add visits)
+                        const uint32_t eb = f2u(q0.w);
+                        const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
+                                    az = u2f(((eb >> 16) & 0xffu) << 23) * id.z;
+                        const float bx = (q0.x - ro.x) * id.x, by = (q0.y - ro.y) * id.y, bz = (q0.z - ro.z) * id.z;
+                        const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
+                        const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
+                        const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
+                        r0 = f2u(q3.x); r1 = f2u(q3.y); r2 = f2u(q3.z); r3 = f2u(q3.w);
+#define VKR_PLANES(W, A, B, P01, P23)                                                                               \
+    const f2v P01 = pk_fma(f2v{ubyte_f(W, 0), ubyte_f(W, 1)}, A, B), P23 = pk_fma(f2v{ubyte_f(W, 2), ubyte_f(W, 3)}, A, B);
+                        VKR_PLANES(nx4, ax, bx, nx01, nx23) VKR_PLANES(ny4, ay, by, ny01, ny23) VKR_PLANES(nz4, az, bz, nz01, nz23)
+                        VKR_PLANES(fx4, ax, bx, fx01, fx23) VKR_PLANES(fy4, ay, by, fy01, fy23) VKR_PLANES(fz4, az, bz, fz01, fz23)
+#undef VKR_PLANES
+#define VKR_SLABQ(HC, NX, NY, NZ, FX, FY, FZ)                                                                       \
+    {                                                                                                               \
+        float tn = __builtin_fmaxf(__builtin_fmaxf(NX, NY), NZ);                                                    \
+        float tf = __builtin_fminf(__builtin_fminf(FX, FY), FZ);                                                    \
+        tn = __builtin_fmaxf(tn - __builtin_fabsf(tn) * 1e-6f, tmin);                                               \
+        tf = __builtin_fminf(tf + __builtin_fabsf(tf) * 1e-6f, tb);                                                 \
+        HC = (tn <= tf);                                                                                            \
+    }
+                        VKR_SLABQ(h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)
+                        VKR_SLABQ(h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)
+                        VKR_SLABQ(h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)
+                        VKR_SLABQ(h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
+#undef VKR_SLABQ
+                    }
+                }
+#define VKR_APPEND(HC, RC)                                                                                          \
+    {                                                                                                               \
+        const bool isl = (int)RC < 0;                                                                               \
+        const unsigned long long mn = __ballot(HC && !isl), ml = __ballot(HC && isl);                               \
+        if (HC) {                                                                                                   \
+            if (isl) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqr[ix] = (uint16_t)ray; }            \
+            else s_nq[nq + mbcnt64(mn)] = (ray << KQ_NODE_BITS) | RC;                                               \
+        }                                                                                                           \
+        nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
+    }
+                VKR_APPEND(h0, r0) VKR_APPEND(h1, r1) VKR_APPEND(h2, r2) VKR_APPEND(h3, r3)
+#undef VKR_APPEND
+            }
+        }
+
+        // ------------------------------------------------------------------ phase 3: per pixel
+        if (MODE == 0) {
+            if (pvalid) {
+                const uint32_t i = pix0 + (uint32_t)lane;
+                float visSum = 0.0f;
+                for (int k = 0; k < n_samples; ++k) {                                // :252-257
+                    const uint32_t r = (uint32_t)k * 64u + (uint32_t)lane;
+                    visSum += ((s_occ[r >> 5] >> (r & 31u)) & 1u) ? 0.0f : 1.0f;
+                }
+                if (hard) sa.out[i] = visSum > 0.5f ? 1.0f : 0.2f;                   // :233-235
+                else sa.out[i] = mixf(0.0f, 1.0f, visSum / (float)n_samples);        // :258-259
+            }
+        } else {
+            for (int j = 0; j < SQ_POINT_PIX / 64; ++j) {
+                const uint32_t r = (uint32_t)j * 64u + (uint32_t)lane;
+                const uint32_t i = pix0 + r;
+                if (i < sa.count && slice[(size_t)r * 3u].w >= 0.0f)
+                    sa.out[i] = ((s_occ[r >> 5] >> (r & 31u)) & 1u) ? 0.0f : 1.0f;   // :182-195
+            }
+        }
+    }
+}
+
+static hipError_t shadow_q_launch(vkr_ctx* c, int mode, const ShadowArgs& sa, hipStream_t st)
+{
+    hipError_t e;
+    const uint32_t per = mode == 0 ? 64u : (uint32_t)SQ_POINT_PIX;
+    const uint32_t n_chunks = (sa.count + per - 1u) / per;
+    int per_cu = 0;
+    if (mode == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_q<0>, 64, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_q<1>, 64, 0);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
+    if (blocks > n_chunks) blocks = n_chunks;
+    const size_t need = mode == 0 ? 1 : (size_t)blocks * SQ_POINT_PIX * 3;
+    if (c->d_raybuf.n < need) {
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
+    }
+    if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(1)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
+    if (mode == 0) k_shadow_q<0><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_raybuf.p, c->d_tile_counter.p);
+    else k_shadow_q<1><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_raybuf.p, c->d_tile_counter.p);
+    return hipGetLastError();
+}
+
 hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
                              const float L[3], float radius, float samples, float* out, hipStream_t st)
 {
     if (count == 0) return hipSuccess;
+    if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
+        ShadowArgs sa{wp, ng, valid, count, V3{L[0], L[1], L[2]}, radius, samples, V3{0, 0, 0}, out};
+        return shadow_q_launch(c, 0, sa, st);
+    }
     k_shadow_sun<<<(count + VKR_TRACE_BLOCK - 1) / VKR_TRACE_BLOCK, VKR_TRACE_BLOCK, 0, st>>>(
         scene_dev(c), wp, ng, valid, count, V3{L[0], L[1], L[2]}, radius, samples, out);
     return hipGetLastError();
@@ -144,6 +443,10 @@ hipError_t shadow_point_launch(vkr_ctx* c, const float* wp, const float* ng, con
                                const float P[3], float* out, hipStream_t st)
 {
     if (count == 0) return hipSuccess;
+    if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
+        ShadowArgs sa{wp, ng, valid, count, V3{0, 0, 1}, 0.0f, 1.0f, V3{P[0], P[1], P[2]}, out};
+        return shadow_q_launch(c, 1, sa, st);
+    }
     k_shadow_point<<<(count + VKR_TRACE_BLOCK - 1) / VKR_TRACE_BLOCK, VKR_TRACE_BLOCK, 0, st>>>(
         scene_dev(c), wp, ng, valid, count, V3{P[0], P[1], P[2]}, out);
     return hipGetLastError();
