@@ -554,8 +554,16 @@ __host__ __device__ inline QSliceLayout q_slice_layout(int rayCount)
     return l;
 }
 
+// Occupancy of k_trace_q is set by LDS and VGPRs together; measured best on MI355X at 8 rays/px: 640 node items
+// (7.3 KB of LDS per wave -> 22 waves per CU) and a VGPR budget for 6 waves per SIMD.
+#ifndef VKR_Q_WAVES
+#define VKR_Q_WAVES 6
+#endif
+#ifndef K1_NQ
+#define K1_NQ 640
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams fp, const uint16_t* depthP,
+__global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_WAVES, VKR_Q_WAVES))) void k_trace_q(SceneDev sc, FrameParams fp, const uint16_t* depthP,
                                                       const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
                                                       int y0, int y1, uint32_t tiles_x, uint32_t n_tiles, float4* rayBuf,
                                                       uint32_t* tile_counter, unsigned long long* stats)
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
     const int rayCount = fp.rayCount;                                           // :252
     uint32_t* s_tbest = smem;                                                   // [rayCount * 64] closest hit, float bits
     uint32_t* s_nq = smem + (uint32_t)rayCount * 64u;                           // node items: ray << 22 | node
-    uint32_t* s_lq = s_nq + KQ_NQ;                                              // leaf items: leaf reference ...
+    uint32_t* s_lq = s_nq + K1_NQ;                                              // leaf items: leaf reference ...
     uint16_t* s_lqr = (uint16_t*)(s_lq + KQ_LQ);                                // ... and its ray
     uint32_t* s_aq = (uint32_t*)(s_lqr + KQ_LQ);                                // MASK candidates: triangle index ...
     uint16_t* s_aqr = (uint16_t*)(s_aq + KQ_AQ);                                // ... and its ray
@@ -711,7 +719,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace_q(SceneDev sc, FrameParams f
                 // ---------------- node step: pops n, pushes <= 4n node items (and <= 4n leaf items, lq < 64 here)
                 uint32_t n = nq < 64u ? nq : 64u;
                 {
-                    const uint32_t room = (uint32_t)KQ_NQ - KQ_GUARD - (nq < (uint32_t)KQ_NQ - KQ_GUARD ? nq : (uint32_t)KQ_NQ - KQ_GUARD);
+                    const uint32_t room = (uint32_t)K1_NQ - KQ_GUARD - (nq < (uint32_t)K1_NQ - KQ_GUARD ? nq : (uint32_t)K1_NQ - KQ_GUARD);
                     const uint32_t fit = room / 3u;
                     if (n > fit) n = fit ? fit : 1u;
                 }
@@ -853,7 +861,7 @@ hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* 
     hipError_t e;
     if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
         // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
-        const size_t lds = (size_t)fp.rayCount * 64u * 4u + (size_t)KQ_NQ * 4u + (size_t)KQ_LQ * 6u + (size_t)KQ_AQ * 6u;
+        const size_t lds = (size_t)fp.rayCount * 64u * 4u + (size_t)K1_NQ * 4u + (size_t)KQ_LQ * 6u + (size_t)KQ_AQ * 6u;
         int per_cu = 0;
         if (c->stats_enabled) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<true>, K1_BLOCK, lds);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false>, K1_BLOCK, lds);
