@@ -148,6 +148,28 @@ VKR_API int vkr_bvh_build(vkr_ctx* ctx, void* stream);
  * mesh indices must be unchanged, else VKR_ERR_INVALID_ARG (reference throws "instance count mismatch", :51-53). */
 VKR_API int vkr_bvh_refit(vkr_ctx* ctx, const vkr_instance* instances, uint32_t count, void* stream);
 
+/* One Node of the model's scene graph (Node::getLocalMatrix / children / meshIndices), in DFS pre-order -- the order
+ * Renderer::rebuildRayTracingInstances visits them (Renderer.cpp:510-524), so parents precede their children. */
+typedef struct vkr_scene_node {
+    int32_t parent;          /* index of the parent node, -1 for a root node (parent < own index)                 */
+    float local[16];         /* Node::getLocalMatrix(), GLM column-major                                          */
+    uint32_t first_instance; /* the node's meshIndices became instances [first_instance, first_instance + count)  */
+    uint32_t instance_count; /*   of the vkr_scene_desc instance list (one instance per (node, mesh), DFS order)  */
+} vkr_scene_node;
+
+/* SURVEY 8(f) row 1.  Replaces the CPU walk of Renderer::rebuildRayTracingInstances (Renderer.cpp:503-527, the
+ * reference's documented CPU hot spot): upload the hierarchy once (HOST array, copied) ... */
+VKR_API int vkr_hierarchy_upload(vkr_ctx* ctx, const vkr_scene_node* nodes, uint32_t node_count);
+/* ... then per frame hand over only the model matrix (GLM column-major).  Mirrors the TLAS cache of
+ * Renderer::recordCommandBuffer (Renderer.cpp:470-479): if the matrix equals the one of the last call nothing is
+ * done and *refitted = 0; otherwise a kernel recomputes worldFromNode = parentWorld * local down the hierarchy,
+ * writes the instance transforms (toVkTransformMatrix, RayTracingContext.cpp:28-44) on the device and refits the
+ * BVH like vkr_bvh_refit (RayTracingContext::updateTopLevelAS), *refitted = 1.  `refitted` may be NULL. */
+VKR_API int vkr_bvh_refit_model(vkr_ctx* ctx, const float model_matrix[16], int* refitted, void* stream);
+/* Copies the current device-side instance transforms (instance_count x 12 floats, 3x4 row-major) to HOST memory:
+ * inspection/tests only (synchronises). */
+VKR_API int vkr_instances_download(vkr_ctx* ctx, float* out_transforms);
+
 typedef struct vkr_bvh_info {
     uint32_t triangle_count; /* flattened world-space triangles                      */
     uint32_t node_count;     /* wide (4-ary) nodes                                   */

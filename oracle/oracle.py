@@ -215,6 +215,30 @@ class OracleScene:
         return float(self.L.orc_shadow_ray(self.handle, _p(oa), _p(da)))
 
 
+class _Node(C.Structure):
+    _fields_ = [("parent", C.c_int32), ("local", C.c_float * 16), ("first_instance", C.c_uint32),
+                ("instance_count", C.c_uint32)]
+
+
+def instances_from_nodes(parents, locals_, first_instance, instance_count, model):
+    """Renderer::rebuildRayTracingInstances on the CPU -> (N_inst, 12) float32 row-major 3x4 transforms."""
+    n = len(parents)
+    nodes = (_Node * max(1, n))()
+    for i in range(n):
+        nodes[i].parent = int(parents[i])
+        nodes[i].local[:] = [float(x) for x in np.asarray(locals_[i], dtype=np.float32).reshape(16)]
+        nodes[i].first_instance = int(first_instance[i])
+        nodes[i].instance_count = int(instance_count[i])
+    total = int(np.sum(instance_count))
+    out = np.zeros((total, 12), dtype=np.float32)
+    m = _f32(np.asarray(model, dtype=np.float32).reshape(16))
+    L = lib()
+    L.orc_instances_from_nodes.restype = None
+    L.orc_instances_from_nodes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.orc_instances_from_nodes(C.cast(nodes, C.c_void_p), n, _p(m), _p(out))
+    return out
+
+
 def atrous(ubo, step, src, depth, normal, y0=0, y1=None):
     H, W = depth.shape
     out = np.zeros((H, W), dtype=np.uint16)

@@ -1074,6 +1074,37 @@ void orc_gbuffer(void* sp, const float* ubo, int W, int H, uint16_t* depth, uint
 }
 
 // ---- unit taps for known-answer tests -----------------------------------------------------------
+// Renderer::rebuildRayTracingInstances (Renderer.cpp:503-527): DFS over the node hierarchy, worldFromNode =
+// parentWorld * local (GLM scalar mat4 product: column j = ((A0*b0 + A1*b1) + A2*b2) + A3*b3, every product and sum
+// rounded), one instance per (node, mesh index) in DFS order, then toVkTransformMatrix (RayTracingContext.cpp:28-44):
+// 3x4 row-major of the column-major mat4.  nodes: parent index (-1 = root, parents first), local[16], instance range.
+struct orc_node { int32_t parent; float local[16]; uint32_t first_instance, instance_count; };
+static void glm_mul_m4(const float* A, const float* B, float* R)
+{
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 4; ++r) {
+            float acc = A[0 * 4 + r] * B[j * 4 + 0];
+            acc = acc + A[1 * 4 + r] * B[j * 4 + 1];
+            acc = acc + A[2 * 4 + r] * B[j * 4 + 2];
+            acc = acc + A[3 * 4 + r] * B[j * 4 + 3];
+            R[j * 4 + r] = acc;
+        }
+}
+void orc_instances_from_nodes(const orc_node* nodes, uint32_t node_count, const float* model, float* out_xf)
+{
+    std::vector<float> world((size_t)node_count * 16);
+    for (uint32_t n = 0; n < node_count; ++n) {      // parents precede children: the DFS recurrence in array order
+        const float* parentWorld = nodes[n].parent < 0 ? model : &world[(size_t)nodes[n].parent * 16];
+        glm_mul_m4(parentWorld, nodes[n].local, &world[(size_t)n * 16]);
+        const float* m = &world[(size_t)n * 16];
+        for (uint32_t k = 0; k < nodes[n].instance_count; ++k) {
+            float* o = out_xf + (size_t)(nodes[n].first_instance + k) * 12;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 4; ++c) o[r * 4 + c] = m[c * 4 + r];
+        }
+    }
+}
+
 float orc_radical_inverse(uint32_t i) { return radicalInverseVdC(i); }
 void orc_hammersley(uint32_t i, uint32_t n, float out[2]) { V2 h = hammersley(i, n); out[0] = h.x; out[1] = h.y; }
 void orc_offset_ray(const float p[3], const float n[3], float out[3])

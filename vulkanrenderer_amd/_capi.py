@@ -39,6 +39,11 @@ class SceneDesc(C.Structure):
                 ("material_params", C.c_void_p), ("alpha_textures", C.POINTER(AlphaTexture))]
 
 
+class SceneNode(C.Structure):
+    _fields_ = [("parent", C.c_int32), ("local", C.c_float * 16), ("first_instance", C.c_uint32),
+                ("instance_count", C.c_uint32)]
+
+
 class BvhInfo(C.Structure):
     _fields_ = [("triangle_count", C.c_uint32), ("node_count", C.c_uint32), ("height", C.c_uint32),
                 ("morton_bits", C.c_uint32), ("binary_height", C.c_uint32), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3)]
@@ -65,6 +70,9 @@ SYMBOLS = {
     "vkr_scene_upload": (C.c_int, [_P, C.POINTER(SceneDesc)]),
     "vkr_bvh_build": (C.c_int, [_P, _P]),
     "vkr_bvh_refit": (C.c_int, [_P, C.POINTER(Instance), C.c_uint32, _P]),
+    "vkr_hierarchy_upload": (C.c_int, [_P, C.POINTER(SceneNode), C.c_uint32]),
+    "vkr_bvh_refit_model": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int), _P]),
+    "vkr_instances_download": (C.c_int, [_P, _P]),
     "vkr_bvh_info_get": (C.c_int, [_P, C.POINTER(BvhInfo)]),
     "vkr_bvh_download": (C.c_int, [_P, _P, _P]),
     "vkr_rtao_execute": (C.c_int, [_P, C.POINTER(RtaoFrameIO), _P]),

@@ -633,6 +633,61 @@ __global__ void k_single(const float4* tris, float4* nodes, uint4* wide_bref, ui
     ctl->count = 1; ctl->levels = 1; ctl->level_begin = 1; ctl->level_end = 1;
 }
 
+// ---------------------------------------------------------------- scene graph -> instance transforms ----
+// Renderer::rebuildRayTracingInstances (Renderer.cpp:503-527) without the CPU walk: one thread per node climbs to
+// its root, then multiplies parentWorld * local back down in the reference's order (GLM scalar mat4 product, every
+// product and sum rounded -- identical bits to the DFS), and writes toVkTransformMatrix (RayTracingContext.cpp:28-44)
+// for the node's instances.  O(nodes x depth); depth is checked against VKR_GRAPH_MAX_DEPTH on upload.
+struct ModelMat { float m[16]; };
+VKR_DI void glm_mul_m4(const float* A, const float* B, float* R)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc = A[0 * 4 + r] * B[j * 4 + 0];
+            acc = acc + A[1 * 4 + r] * B[j * 4 + 1];
+            acc = acc + A[2 * 4 + r] * B[j * 4 + 2];
+            acc = acc + A[3 * 4 + r] * B[j * 4 + 3];
+            R[j * 4 + r] = acc;
+        }
+}
+
+__global__ __launch_bounds__(64) void k_instances_from_nodes(const vkr_ctx::NodeDev* nodes, uint32_t node_count,
+                                                             ModelMat model, float* inst_xf)
+{
+    const uint32_t n = blockIdx.x * 64u + threadIdx.x;
+    if (n >= node_count) return;
+    if (nodes[n].instance_count == 0u) return;         // inner nodes without meshes contribute through their children
+    int chain[VKR_GRAPH_MAX_DEPTH];
+    int depth = 0;
+    for (int a = (int)n; a >= 0 && depth < VKR_GRAPH_MAX_DEPTH; a = nodes[a].parent) chain[depth++] = a;
+    float world[16], next[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) world[k] = model.m[k];
+    for (int d = depth - 1; d >= 0; --d) {
+        glm_mul_m4(world, nodes[chain[d]].local, next);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) world[k] = next[k];
+    }
+    for (uint32_t k = 0; k < nodes[n].instance_count; ++k) {
+        float* o = inst_xf + (size_t)(nodes[n].first_instance + k) * 12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[r * 4 + c] = world[c * 4 + r];
+    }
+}
+
+hipError_t instances_from_nodes_launch(vkr_ctx* c, const float model[16], hipStream_t st)
+{
+    if (c->graph_nodes == 0) return hipSuccess;
+    ModelMat m;
+    for (int k = 0; k < 16; ++k) m.m[k] = model[k];
+    k_instances_from_nodes<<<(c->graph_nodes + 63u) / 64u, 64, 0, st>>>(c->d_graph.p, c->graph_nodes, m, c->d_inst_xf.p);
+    return hipGetLastError();
+}
+
 #define VKR_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 // Stage 1 of a build (everything up to the binary fit); the host reads back the binary height, then stage 2

@@ -85,6 +85,13 @@ struct vkr_ctx {
     vkr::DevBuf<uint32_t> d_inst_first_tri;  // exclusive prefix of primitives per instance (+1 entry)
     vkr::DevBuf<float> d_inst_xf;            // 12 floats per instance
 
+    // ---- scene graph (Renderer::rebuildRayTracingInstances on the device)
+    struct NodeDev { int32_t parent; uint32_t first_instance, instance_count, pad; float local[16]; };
+    vkr::DevBuf<NodeDev> d_graph;
+    uint32_t graph_nodes = 0;
+    bool has_cached_model = false;
+    float cached_model[16] = {0};
+
     // ---- BVH
     bool has_bvh = false;
     uint32_t morton_bits = 21;
@@ -145,6 +152,7 @@ inline SceneDev scene_dev(const vkr_ctx* c)
 // bvh_build.hip
 hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st);
 hipError_t bvh_wide_launch(vkr_ctx* c, uint32_t bin_height, hipStream_t st);
+hipError_t instances_from_nodes_launch(vkr_ctx* c, const float model[16], hipStream_t st);
 // rtao_kernels.hip
 hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,
                              uint16_t* hist_curr, uint32_t* hit_mask, int y0, int y1, hipStream_t st);

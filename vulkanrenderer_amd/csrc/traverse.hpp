@@ -26,6 +26,7 @@ namespace vkr {
 constexpr int VKR_LDS_STACK = 12;    // entries per lane kept in LDS (2 dwords each)
 constexpr int VKR_MAX_STACK = 96;    // hard cap; the host checks 3*levels+1 against it after every build
 constexpr int VKR_TRACE_BLOCK = 256;
+constexpr int VKR_GRAPH_MAX_DEPTH = 64;   // scene-graph depth accepted by vkr_hierarchy_upload
 constexpr int VKR_LEAF_MAX = 4;      // triangles per leaf (encoding allows 8)
 constexpr uint32_t VKR_CHILD_NONE = 0x7fffffffu;
 #ifndef VKR_LEAF_VOTE

@@ -177,6 +177,8 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     if (int rc = set_device(c)) return rc;
     c->has_scene = false;
     c->has_bvh = false;
+    c->graph_nodes = 0;
+    c->has_cached_model = false;
 
     // merged buffers exactly as FrameManager::createReflectionBuffers builds them (FrameManager.cpp:1264-1304)
     std::vector<float> positions;
@@ -373,6 +375,7 @@ int vkr_bvh_refit(vkr_ctx* c, const vkr_instance* inst, uint32_t count, void* st
         return fail(c, VKR_ERR_INVALID_ARG, "instance count mismatch: RayTracingContext must be re-initialized");
     if (count && !inst) return fail(c, VKR_ERR_INVALID_ARG, "instances is NULL");
     if (int rc = set_device(c)) return rc;
+    c->has_cached_model = false;   // explicit transforms supersede whatever model matrix produced the current ones
     hipStream_t st = (hipStream_t)stream;
     std::vector<float> xf((size_t)count * 12);
     for (uint32_t i = 0; i < count; ++i) {
@@ -387,6 +390,77 @@ int vkr_bvh_refit(vkr_ctx* c, const vkr_instance* inst, uint32_t count, void* st
     if (c->tri_count == 0) return VKR_OK;
     HIP_OR_FAIL(c, bvh_build_launch(c, true, st));
     c->bounds_dirty = true;   // the refit recomputed the scene bounds on the device; info_get fetches them on demand
+    return VKR_OK;
+}
+
+int vkr_hierarchy_upload(vkr_ctx* c, const vkr_scene_node* nodes, uint32_t node_count)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!c->has_scene) return fail(c, VKR_ERR_STATE, "vkr_hierarchy_upload before vkr_scene_upload");
+    if (node_count && !nodes) return fail(c, VKR_ERR_INVALID_ARG, "nodes is NULL");
+    if (int rc = set_device(c)) return rc;
+    c->graph_nodes = 0;
+    c->has_cached_model = false;
+    std::vector<vkr_ctx::NodeDev> h(node_count);
+    std::vector<int> depth(node_count, 0);
+    uint32_t running = 0;
+    for (uint32_t i = 0; i < node_count; ++i) {
+        const vkr_scene_node& n = nodes[i];
+        if (n.parent >= (int32_t)i || n.parent < -1)
+            return fail(c, VKR_ERR_INVALID_ARG, "node %u: parent %d must precede it (DFS pre-order)", i, n.parent);
+        depth[i] = n.parent < 0 ? 1 : depth[n.parent] + 1;
+        if (depth[i] > VKR_GRAPH_MAX_DEPTH) return fail(c, VKR_ERR_LIMIT, "node %u: hierarchy deeper than %d", i, VKR_GRAPH_MAX_DEPTH);
+        // one instance per (node, meshIndex) in visiting order (Renderer.cpp:514-519): ranges tile [0, instance_count)
+        if (n.first_instance != running)
+            return fail(c, VKR_ERR_INVALID_ARG, "node %u: first_instance %u breaks DFS instance order (expected %u)", i,
+                        n.first_instance, running);
+        running += n.instance_count;
+        h[i].parent = n.parent; h[i].first_instance = n.first_instance; h[i].instance_count = n.instance_count; h[i].pad = 0;
+        memcpy(h[i].local, n.local, 64);
+    }
+    if (running != c->instance_count)   // RayTracingContext.cpp:51-53
+        return fail(c, VKR_ERR_INVALID_ARG, "instance count mismatch: hierarchy yields %u instances, scene has %u", running,
+                    c->instance_count);
+    HIP_OR_FAIL(c, c->d_graph.alloc(node_count ? node_count : 1));
+    if (node_count) HIP_OR_FAIL(c, hipMemcpy(c->d_graph.p, h.data(), h.size() * sizeof(h[0]), hipMemcpyHostToDevice));
+    c->graph_nodes = node_count;
+    return VKR_OK;
+}
+
+int vkr_bvh_refit_model(vkr_ctx* c, const float model[16], int* refitted, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (refitted) *refitted = 0;
+    if (!model) return fail(c, VKR_ERR_INVALID_ARG, "model_matrix is NULL");
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_bvh_refit_model before vkr_bvh_build");
+    if (c->graph_nodes == 0 && c->instance_count != 0)
+        return fail(c, VKR_ERR_STATE, "vkr_bvh_refit_model before vkr_hierarchy_upload");
+    // Renderer.cpp:471-474: glm::mat4 operator!= (float compare, so -0 == 0 and NaN != NaN)
+    bool same = c->has_cached_model;
+    for (int k = 0; k < 16 && same; ++k) same = (c->cached_model[k] == model[k]);
+    if (same) return VKR_OK;
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OR_FAIL(c, instances_from_nodes_launch(c, model, st));
+    if (c->tri_count != 0) {
+        HIP_OR_FAIL(c, bvh_build_launch(c, true, st));
+        c->bounds_dirty = true;
+    }
+    memcpy(c->cached_model, model, 64);
+    c->has_cached_model = true;
+    if (refitted) *refitted = 1;
+    return VKR_OK;
+}
+
+int vkr_instances_download(vkr_ctx* c, float* out)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
+    if (!c->has_scene) return fail(c, VKR_ERR_STATE, "no scene");
+    if (int rc = set_device(c)) return rc;
+    HIP_OR_FAIL(c, hipDeviceSynchronize());
+    if (c->instance_count)
+        HIP_OR_FAIL(c, hipMemcpy(out, c->d_inst_xf.p, (size_t)c->instance_count * 48, hipMemcpyDeviceToHost));
     return VKR_OK;
 }
 

@@ -146,6 +146,34 @@ class RayTracingContext:
         inst = instances_to_array(instance_mesh, instance_transform)
         _check(c.handle, c.lib.vkr_bvh_refit(c.handle, inst, len(instance_mesh), c.stream()), "vkr_bvh_refit")
 
+    def setHierarchy(self, parents, locals_, first_instance, instance_count):
+        """Upload the model's node hierarchy (DFS pre-order) once: Renderer::rebuildRayTracingInstances
+        (Renderer.cpp:503-527) then runs on the device."""
+        c = self.ctx
+        n = len(parents)
+        nodes = (_capi.SceneNode * max(1, n))()
+        for i in range(n):
+            nodes[i].parent = int(parents[i])
+            nodes[i].local[:] = [float(x) for x in np.asarray(locals_[i], dtype=np.float32).reshape(16)]
+            nodes[i].first_instance = int(first_instance[i])
+            nodes[i].instance_count = int(instance_count[i])
+        _check(c.handle, c.lib.vkr_hierarchy_upload(c.handle, nodes, n), "vkr_hierarchy_upload")
+
+    def updateFromModelMatrix(self, model_matrix) -> bool:
+        """The TLAS cache of Renderer::recordCommandBuffer (Renderer.cpp:470-479): refit only when the model matrix
+        changed.  Returns whether a refit was enqueued."""
+        c = self.ctx
+        m = (C.c_float * 16)(*[float(x) for x in np.asarray(model_matrix, dtype=np.float32).reshape(16)])
+        did = C.c_int(0)
+        _check(c.handle, c.lib.vkr_bvh_refit_model(c.handle, m, C.byref(did), c.stream()), "vkr_bvh_refit_model")
+        return bool(did.value)
+
+    def instanceTransforms(self) -> np.ndarray:
+        c = self.ctx
+        out = np.zeros((max(1, len(self.instance_mesh)), 12), dtype=np.float32)
+        _check(c.handle, c.lib.vkr_instances_download(c.handle, out.ctypes.data), "vkr_instances_download")
+        return out[:len(self.instance_mesh)]
+
     def info(self) -> _capi.BvhInfo:
         c = self.ctx
         out = _capi.BvhInfo()

@@ -305,6 +305,58 @@ def make_street_scene(seed: int, detail: float = 1.0, name: str = "street") -> S
     return scene
 
 
+def make_scene_graph(scene: SceneData, seed: int = 1, group_size: int = 6, max_depth: int = 4):
+    """A glTF-like node hierarchy over the scene's instances, in DFS pre-order (the order
+    Renderer::rebuildRayTracingInstances visits nodes, Renderer.cpp:510-524): nested group nodes with their own
+    translations, leaf nodes carrying 1-3 consecutive instances.  With the identity model matrix the hierarchy
+    reproduces scene.instance_transform up to float rounding.
+    Returns (parent[int32], local[(N,16) float32 column-major], first_instance[uint32], instance_count[uint32])."""
+    rng = np.random.default_rng(seed)
+    n_inst = len(scene.instance_mesh)
+    parents, locals_, firsts, counts = [], [], [], []
+
+    def m4_of(xf12):
+        m = np.eye(4, dtype=np.float64)
+        m[:3, :4] = np.asarray(xf12, dtype=np.float64).reshape(3, 4)
+        return m
+
+    def emit(parent, local4, first, count):
+        parents.append(parent)
+        locals_.append(np.ascontiguousarray(local4.T, dtype=np.float32).reshape(16))   # column-major
+        firsts.append(first)
+        counts.append(count)
+        return len(parents) - 1
+
+    cursor = 0
+
+    def build(parent, parent_world, lo, hi, depth):
+        nonlocal cursor
+        if hi - lo <= group_size or depth >= max_depth:
+            i = lo
+            while i < hi:
+                c = int(min(hi - i, rng.integers(1, 4)))
+                # instances of one node share the node's transform in the reference; keep the first one's
+                world = m4_of(scene.instance_transform[i])
+                emit(parent, np.linalg.inv(parent_world) @ world, cursor, c)
+                cursor += c
+                i += c
+            return
+        parts = int(rng.integers(2, 5))
+        cuts = np.linspace(lo, hi, parts + 1).astype(int)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if a == b:
+                continue
+            t = np.eye(4)
+            t[:3, 3] = rng.uniform(-3.0, 3.0, 3)
+            g = emit(parent, t, cursor, 0)
+            build(g, parent_world @ t, a, b, depth + 1)
+
+    build(-1, np.eye(4), 0, n_inst, 0)
+    assert cursor == n_inst
+    return (np.asarray(parents, dtype=np.int32), np.stack(locals_).astype(np.float32),
+            np.asarray(firsts, dtype=np.uint32), np.asarray(counts, dtype=np.uint32))
+
+
 def make_bistro_class(seed: int = 0xB1572026) -> SceneData:
     return make_street_scene(seed, 1.0, "bistro-class")
 
