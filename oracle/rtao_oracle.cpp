@@ -743,7 +743,9 @@ static void atrous_pixel(const float* ubo, int W, int H, int stepIn, const uint1
     float radius = gmax(ubo[96 + 2], 0.01f);                                   // :100
     float sigmaAbs = gmax(0.01f, radius * 0.05f);                              // :101
     const float sigmaRel = 0.0025f;                                            // :102
+    const float invSigmaAbs = 1.0f / sigmaAbs, invSigmaRel = 1.0f / sigmaRel;
     float stepScale = 1.0f + 0.25f * (float)step;                              // :104
+    const float invZden = 1.0f / gmax(centerZ, 1e-3f);
     for (int y = -2; y <= 2; ++y) {                                            // :78-112
         for (int x = -2; x <= 2; ++x) {
             int tx = iclamp(px + x * step, 0, W - 1), ty = iclamp(py + y * step, 0, H - 1);  // :80-81
@@ -754,8 +756,10 @@ static void atrous_pixel(const float* ubo, int W, int H, int stepIn, const uint1
             float tapZ = gmax(half_to_float(depth[to]), 1e-3f);                // :92-93
             V3 tapN = decodeNormalSafe(normal, W, tx, ty);                     // :94
             float dz = fabsf(tapZ - centerZ);                                  // :98
-            float dzRel = dz / gmax(centerZ, 1e-3f);                           // :99
-            float depthNorm = gmax(dz / sigmaAbs, dzRel / sigmaRel);           // :103
+            // GLSL `/` may be a reciprocal multiply (2.5 ULP); the contract takes that form for the three
+            // per-tap quotients, with the reciprocals correctly rounded
+            float dzRel = dz * invZden;                                        // :99
+            float depthNorm = gmax(dz * invSigmaAbs, dzRel * invSigmaRel);     // :103
             depthNorm *= stepScale;                                            // :104
             float depthWeight = det_exp(-depthNorm * depthNorm);               // :105
             float normalWeight = pow32(gclamp(dot3(centerN, tapN), 0.0f, 1.0f));  // :107

@@ -946,7 +946,10 @@ __global__ __launch_bounds__(256) void k_atrous(const uint16_t* src, const float
     float sum = 0.0f, weightSum = 0.0f;
     const float sigmaRel = 0.0025f;                                             // :102
     float stepScale = 1.0f + 0.25f * (float)step;                               // :104
-    float zden = gmax(centerZ, 1e-3f);
+    // GLSL `/` may be a reciprocal multiply (2.5 ULP): the contract takes that form for the three per-tap quotients,
+    // with correctly rounded reciprocals -- 25 x 3 IEEE divisions were a third of this kernel
+    const float invZden = 1.0f / gmax(centerZ, 1e-3f);
+    const float invSigmaAbs = 1.0f / sigmaAbs, invSigmaRel = 1.0f / sigmaRel;
 #pragma unroll
     for (int y = -2; y <= 2; ++y) {                                             // :78-112
         int ty = iclamp(py + y * step, 0, H - 1);
@@ -959,8 +962,8 @@ __global__ __launch_bounds__(256) void k_atrous(const uint16_t* src, const float
             float spatial = det_exp(-0.5f * (float)(x * x + y * y));            // :90
             float range = det_exp(-__builtin_fabsf(s - center) * 8.0f);         // :91
             float dz = __builtin_fabsf(tn.w - centerZ);                         // :98
-            float dzRel = dz / zden;                                            // :99
-            float depthNorm = gmax(dz / sigmaAbs, dzRel / sigmaRel);            // :103
+            float dzRel = dz * invZden;                                         // :99
+            float depthNorm = gmax(dz * invSigmaAbs, dzRel * invSigmaRel);      // :103
             depthNorm *= stepScale;                                             // :104
             float depthWeight = det_exp(-depthNorm * depthNorm);                // :105
             float normalWeight = pow32(gclamp(dot3(centerN, V3{tn.x, tn.y, tn.z}), 0.0f, 1.0f));  // :107
