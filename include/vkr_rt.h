@@ -106,6 +106,9 @@ typedef struct vkr_mesh_desc {
                                   (Renderer.cpp:83-86, FrameManager.cpp:1280-1283)                */
     uint32_t opaque;           /* meshOpaqueFlags[i] (Renderer.cpp:80-87): BLAS geometry eOpaque flag
                                   (RayTracingContext.cpp:226-227)                                 */
+    const void* normals;       /* float3 vertex normal (Vertex.h: offset 12); may be NULL: the G-buffer producer then
+                                  falls back to the triangle's geometric normal.  Only vkr_gbuffer_primary reads it */
+    uint32_t normal_stride;    /* bytes between normals                                           */
 } vkr_mesh_desc;
 
 /* RayTracingInstanceDesc (RayTracingContext.h:10-13) after toVkTransformMatrix (RayTracingContext.cpp:28-44):
@@ -256,9 +259,11 @@ VKR_API int vkr_shadow_point(vkr_ctx* ctx, const float* world_pos, const float* 
 
 /* SURVEY 8(f) row 2 (input side of the path): stands in for DepthPrepass (depth_prepass.vert:42-52,
  * depth_only.frag:20-35) by casting one primary ray per pixel centre through the same BVH.
- * Outputs (device, any may be NULL): linear view-Z R16F (0 = sky), normal*0.5+0.5 RGBA16F
- * (clear value (0.5,0.5,1,1), DepthPrepass.cpp:36), world position float3, geometric normal float3
- * (flipped to face the camera, pbr.frag:339-346), valid uint8. */
+ * Outputs (device, any may be NULL): linear view-Z R16F (0 = sky); normal*0.5+0.5 RGBA16F with
+ * normal = normalize(interpolated normalize(transpose(inverse(mat3(model))) * vertex normal)) as depth_prepass.vert:47-48
+ * and depth_only.frag:31-33 produce it (clear value (0.5,0.5,1,1), DepthPrepass.cpp:36); world position float3;
+ * Ng float3 = the same interpolated normal, negated on back faces (pbr.frag:339-346); valid uint8.
+ * MASK texels below the cutoff are holes (depth_only.frag:22-29), BLEND geometry is not in the prepass. */
 VKR_API int vkr_gbuffer_primary(vkr_ctx* ctx, const float ubo[VKR_UBO_FLOATS], uint16_t* linear_depth_r16f,
                                 uint16_t* normal_rgba16f, float* world_pos, float* geom_normal, uint8_t* valid,
                                 void* stream);

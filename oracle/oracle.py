@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 class _Mesh(C.Structure):
     _fields_ = [("positions", C.c_void_p), ("position_stride", C.c_uint32), ("vertex_count", C.c_uint32),
                 ("indices", C.c_void_p), ("index_count", C.c_uint32), ("uvs", C.c_void_p), ("uv_stride", C.c_uint32),
-                ("material_index", C.c_int32), ("opaque", C.c_uint32)]
+                ("material_index", C.c_int32), ("opaque", C.c_uint32),
+                ("normals", C.c_void_p), ("normal_stride", C.c_uint32)]
 
 
 class _Instance(C.Structure):
@@ -128,6 +129,8 @@ class OracleScene:
             meshes[i].uv_stride = v.shape[1] * 4
             meshes[i].material_index = int(m.material_index)
             meshes[i].opaque = int(opaque[i])
+            meshes[i].normals = v.ctypes.data + 12
+            meshes[i].normal_stride = v.shape[1] * 4
         inst = _instances(scene.instance_mesh, scene.instance_transform)
         mp = _f32(scene.material_params())
         tex = (_Alpha * 256)()

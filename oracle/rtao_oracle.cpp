@@ -178,6 +178,7 @@ struct Tri {
     V3 v0, e1, e2;
     uint32_t mesh, prim, flat;
     uint32_t opaque;  // BLAS geometry opaque flag of the mesh (RayTracingContext.cpp:226-227)
+    uint32_t inst;    // instance it came from (normal matrix of the G-buffer producer)
 };
 
 struct BNode {
@@ -197,6 +198,9 @@ struct Scene {
     std::vector<float> positions;  // merged xyz
     std::vector<uint32_t> indices; // merged, GLOBAL vertex ids (voff + idx)
     std::vector<V2> uvs;           // merged
+    std::vector<float> normals;    // merged xyz vertex normals (Vertex.h offset 12); has_normals per mesh
+    std::vector<uint32_t> mesh_has_normals;
+    std::vector<float> inst_xf;    // current 3x4 row-major transforms
     float material_params[256 * 4];
     AlphaTex tex[256];
     std::vector<uint32_t> inst_mesh;
@@ -292,6 +296,7 @@ static void flatten(Scene& s, const float* inst_xf)
     // one world-space triangle per (instance, primitive); empty meshes contribute nothing
     // (RayTracingContext.cpp:206-208,230-233).  flat id = running index in instance-major order.
     s.tris.clear();
+    s.inst_xf.assign(inst_xf, inst_xf + 12 * s.inst_mesh.size());
     uint32_t flat = 0;
     for (size_t i = 0; i < s.inst_mesh.size(); ++i) {
         uint32_t m = s.inst_mesh[i];
@@ -306,7 +311,7 @@ static void flatten(Scene& s, const float* inst_xf)
             }
             Tri t;
             t.v0 = v[0]; t.e1 = v[1] - v[0]; t.e2 = v[2] - v[0];
-            t.mesh = m; t.prim = p; t.flat = flat++; t.opaque = s.mesh_opaque[m];
+            t.mesh = m; t.prim = p; t.flat = flat++; t.opaque = s.mesh_opaque[m]; t.inst = (uint32_t)i;
             s.tris.push_back(t);
         }
     }
@@ -843,6 +848,7 @@ struct orc_mesh_desc {
     const uint32_t* indices; uint32_t index_count;
     const void* uvs; uint32_t uv_stride;
     int32_t material_index; uint32_t opaque;
+    const void* normals; uint32_t normal_stride;
 };
 struct orc_instance { uint32_t mesh_index; float transform[12]; };
 struct orc_alpha_texture { const uint8_t* alpha; uint32_t width, height; };
@@ -875,7 +881,14 @@ void* orc_scene_create(const orc_scene_desc* d, int brute_force)
             } else {
                 s->uvs.push_back(V2{0, 0});
             }
+            if (md.normals) {
+                const float* n = (const float*)((const char*)md.normals + (size_t)v * md.normal_stride);
+                s->normals.push_back(n[0]); s->normals.push_back(n[1]); s->normals.push_back(n[2]);
+            } else {
+                s->normals.push_back(0.0f); s->normals.push_back(1.0f); s->normals.push_back(0.0f);
+            }
         }
+        s->mesh_has_normals.push_back(md.normals ? 1u : 0u);
         for (uint32_t i = 0; i < md.index_count; ++i) s->indices.push_back(voff + md.indices[i]);  // :1296-1304
         voff += md.vertex_count;
         ioff += md.index_count;
@@ -1029,6 +1042,25 @@ void orc_shadow_point(void* sp, const float* worldPos, const float* geomNormal, 
 
 // G-buffer stand-in for DepthPrepass (depth_prepass.vert:42-52, depth_only.frag:20-35): one primary ray per
 // pixel centre; linear view-Z = -(view*worldPos).z -> R16F; normal = geometric normal*0.5+0.5 -> RGBA16F.
+// transpose(inverse(mat3(model))) up to a positive factor (depth_prepass.vert:47; the result is normalised anyway):
+// cofactors in double from the instance's 3x4 row-major transform, sign of the determinant applied, one rounding.
+static void normal_matrix(const float* xf, float* N)
+{
+    const double m[9] = {xf[0], xf[1], xf[2], xf[4], xf[5], xf[6], xf[8], xf[9], xf[10]};
+    double c[9];
+    c[0] = m[4] * m[8] - m[5] * m[7]; c[1] = m[5] * m[6] - m[3] * m[8]; c[2] = m[3] * m[7] - m[4] * m[6];
+    c[3] = m[2] * m[7] - m[1] * m[8]; c[4] = m[0] * m[8] - m[2] * m[6]; c[5] = m[1] * m[6] - m[0] * m[7];
+    c[6] = m[1] * m[5] - m[2] * m[4]; c[7] = m[2] * m[3] - m[0] * m[5]; c[8] = m[0] * m[4] - m[1] * m[3];
+    const double det = (m[0] * c[0] + m[1] * c[1]) + m[2] * c[2];
+    const double sg = det < 0.0 ? -1.0 : 1.0;
+    for (int k = 0; k < 9; ++k) N[k] = (float)(c[k] * sg);
+}
+static V3 world_normal(const float* N, V3 n)
+{
+    return normalize3(V3{(N[0] * n.x + N[1] * n.y) + N[2] * n.z, (N[3] * n.x + N[4] * n.y) + N[5] * n.z,
+                         (N[6] * n.x + N[7] * n.y) + N[8] * n.z});
+}
+
 void orc_gbuffer(void* sp, const float* ubo, int W, int H, uint16_t* depth, uint16_t* normal, float* worldPosOut,
                  float* ngOut, uint8_t* validOut)
 {
@@ -1056,8 +1088,24 @@ void orc_gbuffer(void* sp, const float* ubo, int W, int H, uint16_t* depth, uint
                 mul_m4_v4(ubo + 16, wp.x, wp.y, wp.z, 1.0f, vp);
                 z = -vp[2];
                 const Tri& tr = s.tris[h.tri];
-                n = normalize3(cross3(tr.e1, tr.e2));
-                ng = (dot3(n, cam - wp) < 0.0f) ? neg(n) : n;
+                const V3 nface = normalize3(cross3(tr.e1, tr.e2));
+                n = nface;
+                if (s.mesh_has_normals[tr.mesh]) {
+                    // depth_prepass.vert:47-48 per vertex, rasteriser interpolation, depth_only.frag:31
+                    float N[9];
+                    normal_matrix(&s.inst_xf[12 * (size_t)tr.inst], N);
+                    const uint32_t ioff = s.lut_index_offset[tr.mesh] + 3 * tr.prim;
+                    V3 vn[3];
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t gi = s.indices[ioff + k];
+                        vn[k] = world_normal(N, V3{s.normals[3 * gi], s.normals[3 * gi + 1], s.normals[3 * gi + 2]});
+                    }
+                    const float w0 = (1.0f - h.u) - h.v;
+                    n = normalize3(V3{(vn[0].x * w0 + vn[1].x * h.u) + vn[2].x * h.v, (vn[0].y * w0 + vn[1].y * h.u) + vn[2].y * h.v,
+                                      (vn[0].z * w0 + vn[1].z * h.u) + vn[2].z * h.v});
+                }
+                // pbr.frag:339-346: Ng = interpolated normal, negated on back faces (gl_FrontFacing from the winding)
+                ng = (dot3(nface, cam - wp) < 0.0f) ? neg(n) : n;
             }
             uint16_t zh = float_to_half(z);
             bool valid = hit && half_to_float(zh) > 1e-6f;

@@ -47,7 +47,7 @@ def test_struct_layouts_match_header():
     # sizes follow from the header's field lists (LP64)
     assert C.sizeof(_capi.CreateDesc) == 12
     assert C.sizeof(_capi.Instance) == 4 + 48
-    assert C.sizeof(_capi.MeshDesc) == 56
+    assert C.sizeof(_capi.MeshDesc) == 72
     assert C.sizeof(_capi.AlphaTexture) == 16
     assert C.sizeof(_capi.SceneDesc) == 48
     assert C.sizeof(_capi.BvhInfo) == 5 * 4 + 24

@@ -29,7 +29,7 @@ def test_scene_has_all_material_classes():
 
 
 def test_vertex_layout_matches_reference_vertex_struct():
-    # Vertex = pos3 color3 normal3 uv2 tangent4 = 15 floats / 60 B, texCoord at byte 36 (RayTracingContext.cpp:262-264)
+    # Vertex = pos3 normal3 color3 uv2 tangent4 = 15 floats / 60 B, texCoord at byte 36 (RayTracingContext.cpp:262-264)
     m = S.box_mesh(1, 0)
     assert m.vertices.shape[1] == S.VERTEX_FLOATS == 15 and S.VERTEX_STRIDE == 60 and S.UV_OFFSET_FLOATS == 9
     assert m.indices.dtype == np.uint32 and m.indices.size % 3 == 0 and m.indices.max() < m.vertices.shape[0]

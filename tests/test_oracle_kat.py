@@ -445,3 +445,43 @@ def test_point_shadow_cases(oracle_mod):
     assert osc.shadow_point(wp[:1], ng[:1], valid[:1], np.array((0, 5e-5, 0), dtype=np.float32))[0] == 1.0
     # tMax = dist - bias: an occluder beyond the light does not shadow
     assert osc.shadow_point(wp[:1], ng[:1], valid[:1], np.array((0, 0.5, 0), dtype=np.float32))[0] == 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G-buffer producer: interpolated vertex normals through the instance's normal matrix
+# (depth_prepass.vert:47-48, depth_only.frag:31-33), Ng flipped on back faces (pbr.frag:339-346)
+# ---------------------------------------------------------------------------------------------------------------
+def test_gbuffer_vertex_normals_on_a_scaled_sphere(oracle_mod):
+    from vulkanrenderer_amd.scenes import Material, SceneData, sphere_mesh, trs, FrameState
+    O = oracle_mod
+    sph = sphere_mesh(24, 16, 0)
+    centre, scale = np.array([0.0, 1.0, 6.0]), np.array([2.0, 1.0, 1.5])
+    for mirror in (1.0, -1.0):
+        xf = trs(tuple(centre), (scale[0] * mirror, scale[1], scale[2]))
+        scene = SceneData([sph], [Material()], np.array([0], dtype=np.uint32), np.stack([xf]).astype(np.float32), "s")
+        osc = O.OracleScene(scene)
+        W, H = 96, 64
+        ubo = FrameState(W, H).update((0.0, 1.5, 0.0), tuple(centre + np.array([0.0, 0.5, 0.0])))
+        depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+        v = valid > 0
+        assert v.sum() > 200
+        n = normal.view(np.float16).astype(np.float32)[..., :3] * 2.0 - 1.0
+        # ellipsoid: the analytic normal at p is normalize((p - c) / s^2); the sphere mesh's own centre is its origin
+        c = centre + scale * np.array([0.0, 0.5, 0.0])
+        local = (wp[v] - c) / (scale ** 2)
+        want = local / np.linalg.norm(local, axis=1, keepdims=True)
+        # the generator's winding makes this mesh's vertex normals point inwards; the inverse-transpose must keep
+        # that orientation for the mirrored instance too (sign of the determinant)
+        sgn = np.sign(np.median(np.einsum("ij,ij->i", n[v], want)))
+        assert sgn == -1.0, (mirror, sgn)
+        err = np.abs(n[v] * sgn - want).max(axis=1)
+        assert np.percentile(err, 95) < 0.06, (mirror, np.percentile(err, 95))      # smooth, not faceted
+        # pbr.frag:339-346: Ng = interpolated normal, negated when !gl_FrontFacing.  This mesh is wound inside-out, so
+        # from outside its faces are back faces (Ng = -n, towards the camera); mirroring the instance reverses the
+        # screen-space winding, the faces become front faces and Ng = n points away -- the reference's own behaviour
+        # for mirrored instances, reproduced as is.
+        cam = np.array([0.0, 1.5, 0.0])
+        rel = np.einsum("ij,ij->i", ng[v], n[v])
+        assert np.abs(rel - (-1.0 if mirror > 0 else 1.0)).max() < 5e-3
+        facing = np.einsum("ij,ij->i", ng[v], cam - wp[v]) > 0
+        assert facing.mean() > 0.97 if mirror > 0 else facing.mean() < 0.03

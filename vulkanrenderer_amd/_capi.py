@@ -22,7 +22,8 @@ class MeshDesc(C.Structure):
     _fields_ = [("positions", C.c_void_p), ("position_stride", C.c_uint32), ("vertex_count", C.c_uint32),
                 ("indices", C.c_void_p), ("index_count", C.c_uint32),
                 ("uvs", C.c_void_p), ("uv_stride", C.c_uint32),
-                ("material_index", C.c_int32), ("opaque", C.c_uint32)]
+                ("material_index", C.c_int32), ("opaque", C.c_uint32),
+                ("normals", C.c_void_p), ("normal_stride", C.c_uint32)]
 
 
 class Instance(C.Structure):

@@ -76,6 +76,8 @@ struct vkr_ctx {
     vkr::DevBuf<float> d_positions;          // merged xyz
     vkr::DevBuf<uint32_t> d_indices;         // merged, global vertex ids (FrameManager.cpp:1296-1304)
     vkr::DevBuf<float2> d_uvs;               // merged (FrameManager.cpp:1287-1294)
+    vkr::DevBuf<float> d_normals;            // merged xyz vertex normals (G-buffer producer only)
+    vkr::DevBuf<uint32_t> d_mesh_has_normals;
     vkr::DevBuf<uint2> d_lut;                // InstanceLUTEntry (FrameManager.cpp:1276-1285)
     vkr::DevBuf<uint32_t> d_mesh_class;      // per mesh AO class (0 commit, 1 skip, 2 alpha test)
     vkr::DevBuf<float4> d_material_params;   // 256 x vec4 (FrameManager.cpp:1354-1371)
@@ -146,6 +148,11 @@ inline SceneDev scene_dev(const vkr_ctx* c)
     s.material_params = c->d_material_params.p;
     s.alpha_tex = c->d_alpha_tex.p;
     s.alpha_data = c->d_alpha_data.p;
+    s.normals = c->d_normals.p;
+    s.mesh_has_normals = c->d_mesh_has_normals.p;
+    s.inst_first_tri = c->d_inst_first_tri.p;
+    s.inst_xf = c->d_inst_xf.p;
+    s.instance_count = c->instance_count;
     return s;
 }
 

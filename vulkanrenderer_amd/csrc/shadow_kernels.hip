@@ -78,6 +78,26 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_shadow_point(SceneDev sc, c
     out[i] = traverse<Q_SHADOW, false>(sc, rayOrigin, rayDir, tMin, tMax, nullptr, stack, nullptr) ? 0.0f : 1.0f;
 }
 
+// transpose(inverse(mat3(model))) up to a positive factor (depth_prepass.vert:47; the result is normalised anyway):
+// cofactors in double from the instance's 3x4 row-major transform, sign of the determinant applied, one rounding.
+VKR_DI void normal_matrix(const float* xf, float* N)
+{
+    const double m[9] = {xf[0], xf[1], xf[2], xf[4], xf[5], xf[6], xf[8], xf[9], xf[10]};
+    double c[9];
+    c[0] = m[4] * m[8] - m[5] * m[7]; c[1] = m[5] * m[6] - m[3] * m[8]; c[2] = m[3] * m[7] - m[4] * m[6];
+    c[3] = m[2] * m[7] - m[1] * m[8]; c[4] = m[0] * m[8] - m[2] * m[6]; c[5] = m[1] * m[6] - m[0] * m[7];
+    c[6] = m[1] * m[5] - m[2] * m[4]; c[7] = m[2] * m[3] - m[0] * m[5]; c[8] = m[0] * m[4] - m[1] * m[3];
+    const double det = (m[0] * c[0] + m[1] * c[1]) + m[2] * c[2];
+    const double sg = det < 0.0 ? -1.0 : 1.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) N[k] = (float)(c[k] * sg);
+}
+VKR_DI V3 world_normal(const float* N, V3 n)
+{
+    return normalize3(V3{(N[0] * n.x + N[1] * n.y) + N[2] * n.z, (N[3] * n.x + N[4] * n.y) + N[5] * n.z,
+                         (N[6] * n.x + N[7] * n.y) + N[8] * n.z});
+}
+
 // Primary visibility: what DepthPrepass leaves in linearDepthResolve / normalResolve
 // (depth_prepass.vert:42-52 viewZ = -viewPos.z; depth_only.frag:31-34 normal*0.5+0.5, linear Z), plus the
 // worldPos / Ng varyings pbr.frag shades with (:339-346).
@@ -109,9 +129,32 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer(SceneDev sc, FrameP
         mul_m4_v4(fp.view, wp.x, wp.y, wp.z, 1.0f, vp);
         z = -vp[2];
         const float4* tp = sc.tris + (size_t)h.tri * 3;
-        float4 b = tp[1], c = tp[2];
-        n = normalize3(cross3(V3{b.x, b.y, b.z}, V3{c.x, c.y, c.z}));
-        ng = (dot3(n, cam - wp) < 0.0f) ? neg(n) : n;
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        const V3 nface = normalize3(cross3(V3{b.x, b.y, b.z}, V3{c.x, c.y, c.z}));
+        n = nface;
+        const uint32_t mesh = f2u(a.w) & 0x0fffffffu, prim = f2u(b.w), flat = f2u(c.w);
+        if (sc.mesh_has_normals[mesh]) {
+            // depth_prepass.vert:47-48 per vertex, rasteriser interpolation, depth_only.frag:31
+            uint32_t lo = 0, hi = sc.instance_count;       // instance with inst_first_tri[i] <= flat < inst_first_tri[i+1]
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sc.inst_first_tri[mid] <= flat) lo = mid; else hi = mid;
+            }
+            float N[9];
+            normal_matrix(sc.inst_xf + 12 * (size_t)lo, N);
+            const uint32_t ioff = sc.lut[mesh].y + 3u * prim;
+            V3 vn[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t gi = sc.indices[ioff + k];
+                vn[k] = world_normal(N, V3{sc.normals[3 * (size_t)gi], sc.normals[3 * (size_t)gi + 1], sc.normals[3 * (size_t)gi + 2]});
+            }
+            const float w0 = (1.0f - h.u) - h.v;
+            n = normalize3(V3{(vn[0].x * w0 + vn[1].x * h.u) + vn[2].x * h.v, (vn[0].y * w0 + vn[1].y * h.u) + vn[2].y * h.v,
+                              (vn[0].z * w0 + vn[1].z * h.u) + vn[2].z * h.v});
+        }
+        // pbr.frag:339-346: Ng = interpolated normal, negated on back faces (gl_FrontFacing from the winding)
+        ng = (dot3(nface, cam - wp) < 0.0f) ? neg(n) : n;
     }
     uint16_t zh = float_to_half(z);
     bool valid = hit && half_to_float(zh) > 1e-6f;

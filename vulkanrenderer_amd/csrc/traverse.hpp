@@ -52,6 +52,12 @@ struct SceneDev {
     const float4* material_params;
     const AlphaTexDev* alpha_tex;
     const uint8_t* alpha_data;
+    // G-buffer producer (depth_prepass.vert:47-48): vertex normals and the instance a triangle came from
+    const float* normals;            // merged xyz
+    const uint32_t* mesh_has_normals;
+    const uint32_t* inst_first_tri;  // exclusive prefix of triangles per instance (+1 entry)
+    const float* inst_xf;            // 12 floats per instance
+    uint32_t instance_count;
 };
 
 struct HitDev { float t; uint32_t tri; float u, v; };

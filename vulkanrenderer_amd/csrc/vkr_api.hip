@@ -184,6 +184,8 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     std::vector<float> positions;
     std::vector<uint32_t> indices;
     std::vector<float2> uvs;
+    std::vector<float> normals;
+    std::vector<uint32_t> mesh_has_normals(s->mesh_count);
     std::vector<uint2> lut(s->mesh_count);
     std::vector<uint32_t> mesh_class(s->mesh_count);
     c->h_mesh_prims.assign(s->mesh_count, 0);
@@ -220,7 +222,14 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
             } else {
                 uvs.push_back(make_float2(0.0f, 0.0f));
             }
+            if (md.normals) {
+                const float* nn = (const float*)((const char*)md.normals + (size_t)v * md.normal_stride);
+                normals.push_back(nn[0]); normals.push_back(nn[1]); normals.push_back(nn[2]);
+            } else {
+                normals.push_back(0.0f); normals.push_back(1.0f); normals.push_back(0.0f);   // Vertex.h default
+            }
         }
+        mesh_has_normals[m] = md.normals ? 1u : 0u;
         for (uint32_t i = 0; i < md.index_count; ++i) {
             if (md.indices[i] >= md.vertex_count) return fail(c, VKR_ERR_INVALID_ARG, "mesh %u: index %u out of range", m, i);
             indices.push_back((uint32_t)voff + md.indices[i]);                   // FrameManager.cpp:1299-1303
@@ -270,6 +279,8 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     UPLOAD(c->d_positions, positions);
     UPLOAD(c->d_indices, indices);
     UPLOAD(c->d_uvs, uvs);
+    UPLOAD(c->d_normals, normals);
+    UPLOAD(c->d_mesh_has_normals, mesh_has_normals);
     UPLOAD(c->d_lut, lut);
     UPLOAD(c->d_mesh_class, mesh_class);
     UPLOAD(c->d_alpha_tex, tex);

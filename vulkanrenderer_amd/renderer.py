@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .scenes import SceneData, VERTEX_STRIDE, UV_OFFSET_FLOATS, MAX_MATERIALS
+from .scenes import SceneData, VERTEX_STRIDE, UV_OFFSET_FLOATS, NORMAL_OFFSET_FLOATS, MAX_MATERIALS
 
 
 def _check(ctx_handle, rc: int, what: str):
@@ -55,6 +55,8 @@ def scene_to_desc(scene: SceneData):
         meshes[i].uv_stride = VERTEX_STRIDE
         meshes[i].material_index = int(m.material_index)
         meshes[i].opaque = int(opaque[i])
+        meshes[i].normals = v.ctypes.data + 4 * NORMAL_OFFSET_FLOATS
+        meshes[i].normal_stride = VERTEX_STRIDE
     n_inst = len(scene.instance_mesh)
     inst = (_capi.Instance * max(1, n_inst))()
     for i in range(n_inst):

@@ -20,6 +20,7 @@ import numpy as np
 VERTEX_FLOATS = 15          # sizeof(Vertex) = 60 bytes
 VERTEX_STRIDE = 60
 UV_OFFSET_FLOATS = 9        # texCoord at byte 36
+NORMAL_OFFSET_FLOATS = 3    # normal at byte 12 (Vertex.h: pos, normal, color, texCoord, tangent)
 MAX_MATERIALS = 256         # AppConfig::MAX_REFLECTION_MATERIAL_COUNT
 
 ALPHA_OPAQUE, ALPHA_MASK, ALPHA_BLEND = 0, 1, 2
@@ -30,6 +31,20 @@ class Mesh:
     vertices: np.ndarray        # (V, 15) float32, reference Vertex layout
     indices: np.ndarray         # (I,) uint32, mesh-local
     material_index: int
+
+    def __post_init__(self):
+        # area-weighted vertex normals, as a glTF exporter would have written them (shared vertices come out smooth)
+        v, idx = self.vertices, self.indices.reshape(-1, 3)
+        if len(idx) == 0:
+            return
+        p = v[:, :3].astype(np.float64)
+        fn = np.cross(p[idx[:, 1]] - p[idx[:, 0]], p[idx[:, 2]] - p[idx[:, 0]])
+        acc = np.zeros_like(p)
+        for k in range(3):
+            np.add.at(acc, idx[:, k], fn)
+        ln = np.linalg.norm(acc, axis=1, keepdims=True)
+        acc = np.where(ln > 1e-20, acc / np.maximum(ln, 1e-20), np.array([0.0, 1.0, 0.0]))
+        v[:, 3:6] = acc.astype(np.float32)
 
 
 @dataclass
