@@ -445,6 +445,246 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4, packet form (the default for the sun).  The n sun-disc directions are frame constants and differ by ~0.01 rad,
+// so the n rays of a pixel share their origin and almost their path: ONE traversal per pixel with a conservative
+// slab test over the whole direction set (interval arithmetic on 1/d per axis; an axis whose directions change sign
+// is left unconstrained), and the n rays are told apart only at the leaves, where a triangle is tested against all
+// n directions with the direction-independent parts of Moeller-Trumbore (tvec, qvec, dot(e2, qvec)) computed once.
+// Per ray the arithmetic is that of tri_hit(), so each ray's any-hit answer is exactly the per-ray kernel's; the
+// packet only changes which boxes are opened (a superset).  Same queue machinery as k_shadow_q; a pixel whose n rays
+// are all occluded is dropped.  Node work falls ~n-fold, leaf work per hit triangle rises ~n/2-fold.
+// ---------------------------------------------------------------------------------------------
+constexpr int SP_PIX = 256;            // pixels per chunk (4 per lane)
+constexpr int SP_NQ = 768;
+
+struct SunFrame {                      // written by k_sun_setup, read with scalar loads
+    float dir[16][4];                  // sample directions (pbr.frag:255), w unused
+    float idlo[4], idhi[4];            // per axis: bounds of 1/d over the samples (valid where axis_ok)
+    uint32_t axis_ok[4];               // all samples have the same non-zero sign on this axis
+    uint32_t n, hard, no_light, pad;
+};
+
+__global__ void k_sun_setup(V3 L, float sunRadius, float sampleCountF, SunFrame* out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool no_light = dot3(L, L) < 1e-8f;                                    // :219-222
+    const V3 rayDir = normalize3(L);                                             // :223
+    int n = iclamp((int)(sampleCountF + 0.5f), 1, 16);                           // :228-229
+    const bool hard = (sunRadius <= 0.0f || n <= 1);                             // :232
+    if (hard) n = 1;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int k = 0; k < 16; ++k) {
+        V3 d = rayDir;
+        if (!hard && k < n) {
+            V3 up = (__builtin_fabsf(rayDir.y) < 0.999f) ? v3(0, 1, 0) : v3(0, 0, 1);   // :239
+            V3 T = normalize3(cross3(up, rayDir));                                // :240
+            V3 B = cross3(rayDir, T);                                             // :241
+            float ux = kPoisson[k][0], uy = kPoisson[k][1];
+            V3 offset = V3{sunRadius * (ux * T.x + uy * B.x), sunRadius * (ux * T.y + uy * B.y),
+                           sunRadius * (ux * T.z + uy * B.z)};
+            d = normalize3(rayDir + offset);                                      // :255
+        }
+        out->dir[k][0] = d.x; out->dir[k][1] = d.y; out->dir[k][2] = d.z; out->dir[k][3] = 0.0f;
+        if (k < n) {
+            const float c[3] = {d.x, d.y, d.z};
+            for (int a = 0; a < 3; ++a) { lo[a] = __builtin_fminf(lo[a], c[a]); hi[a] = __builtin_fmaxf(hi[a], c[a]); }
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        const bool ok = (lo[a] > 0.0f) || (hi[a] < 0.0f);       // one sign, never zero
+        out->axis_ok[a] = ok ? 1u : 0u;
+        // 1/d is decreasing on either side of zero: bounds are the reciprocals of the other end, widened a little
+        const float a0 = ok ? 1.0f / hi[a] : 0.0f, a1 = ok ? 1.0f / lo[a] : 0.0f;
+        const float l = __builtin_fminf(a0, a1), h = __builtin_fmaxf(a0, a1);
+        out->idlo[a] = l - __builtin_fabsf(l) * 1e-6f;
+        out->idhi[a] = h + __builtin_fabsf(h) * 1e-6f;
+    }
+    out->axis_ok[3] = 0; out->idlo[3] = 0; out->idhi[3] = 0;
+    out->n = (uint32_t)n; out->hard = hard ? 1u : 0u; out->no_light = no_light ? 1u : 0u; out->pad = 0;
+}
+
+__global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs sa, const SunFrame* __restrict__ sf,
+                                                       uint32_t n_chunks, uint32_t* chunk_counter)
+{
+    __shared__ uint32_t s_nq[SP_NQ];       // node items: pixel << 22 | node
+    __shared__ uint32_t s_lq[KQ_LQ];       // leaf items: leaf reference ...
+    __shared__ uint16_t s_lqp[KQ_LQ];      // ... and its pixel
+    __shared__ uint32_t s_mask[SP_PIX];    // per pixel: bit k = sample k is occluded
+    __shared__ float4 s_org[SP_PIX];       // per pixel: ray origin
+
+    const int lane = threadIdx.x;
+    const char* node_base = (const char*)sc.nodes;
+    const char* tri_base = (const char*)sc.tris;
+    const uint32_t n_dirs = sf->n;
+    const uint32_t full = (n_dirs >= 32u) ? 0xffffffffu : ((1u << n_dirs) - 1u);
+    const bool hard = sf->hard != 0u, no_light = sf->no_light != 0u;
+    const float tmin = 0.001f, tmax = 500.0f;                                    // :203-204
+    const float tb = tmax * 1.000001f;
+    const bool okx = sf->axis_ok[0] != 0u, oky = sf->axis_ok[1] != 0u, okz = sf->axis_ok[2] != 0u;
+    const float ilx = sf->idlo[0], ihx = sf->idhi[0], ily = sf->idlo[1], ihy = sf->idhi[1], ilz = sf->idlo[2], ihz = sf->idhi[2];
+    // near/far plane per axis by the (common) direction sign
+    const bool posx = ihx > 0.0f, posy = ihy > 0.0f, posz = ihz > 0.0f;
+
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(chunk_counter, 1u);
+        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+        if (chunk >= n_chunks) break;        // every wave reaches this: the counter only grows
+        const uint32_t pix0 = chunk * (uint32_t)SP_PIX;
+
+        // ------------------------------------------------------------------ phase 1: origins
+        uint32_t nq = 0, lq = 0;
+        for (int j = 0; j < SP_PIX / 64; ++j) {
+            const uint32_t p = (uint32_t)j * 64u + (uint32_t)lane;
+            const uint32_t i = pix0 + p;
+            bool live = false;
+            if (i < sa.count) {
+                if ((sa.valid && !sa.valid[i]) || no_light) sa.out[i] = 1.0f;
+                else {
+                    V3 worldPos = V3{sa.wp[3 * (size_t)i], sa.wp[3 * (size_t)i + 1], sa.wp[3 * (size_t)i + 2]};
+                    V3 geomNormal = V3{sa.ng[3 * (size_t)i], sa.ng[3 * (size_t)i + 1], sa.ng[3 * (size_t)i + 2]};
+                    V3 rayOrigin = worldPos + geomNormal * 0.002f;                // :224-225
+                    s_org[p] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
+                    live = true;
+                }
+            }
+            s_mask[p] = live ? 0u : 0x80000000u;     // bit 31: no rays from this pixel
+            const unsigned long long lm = __ballot(live && sc.tri_count != 0u);
+            if (live && sc.tri_count != 0u) s_nq[nq + mbcnt64(lm)] = p << KQ_NODE_BITS;   // root
+            nq += (uint32_t)__popcll(lm);
+        }
+
+        // ------------------------------------------------------------------ phase 2: queues
+        for (;;) {
+            if (lq >= 64u || (lq > 0u && nq == 0u)) {
+                // ---------------- leaf step: every triangle of the leaf against all n directions
+                const uint32_t n = lq < 64u ? lq : 64u;
+                lq -= n;
+                uint32_t cntT = 0, first = 0, pix = 0, have = 0;
+                V3 ro = v3(0, 0, 0);
+                if ((uint32_t)lane < n) {
+                    const uint32_t ref = s_lq[lq + (uint32_t)lane];
+                    pix = (uint32_t)s_lqp[lq + (uint32_t)lane];
+                    have = s_mask[pix];
+                    if ((have & full) != full) {
+                        const uint32_t x = ~ref;
+                        first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
+                        const float4 o = s_org[pix];
+                        ro = V3{o.x, o.y, o.z};
+                    }
+                }
+                uint32_t got = 0;
+                for (uint32_t j = 0; j < (uint32_t)VKR_LEAF_MAX; ++j) {
+                    if (__ballot(j < cntT) == 0ull) break;
+                    if (j < cntT) {
+                        const float4* tp = (const float4*)(tri_base + (size_t)(first + j) * 48u);
+                        const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
+                        const V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
+                        // tri_hit() with its direction-independent terms hoisted: same operations, same bits per ray
+                        const V3 tvec = ro - v0;
+                        const V3 qvec = cross3(tvec, e1);
+                        const float te = dot3(e2, qvec);
+                        for (uint32_t k = 0; k < n_dirs; ++k) {
+                            const V3 d = V3{sf->dir[k][0], sf->dir[k][1], sf->dir[k][2]};
+                            const V3 pvec = cross3(d, e2);
+                            const float det = dot3(e1, pvec);
+                            const float inv = 1.0f / det;
+                            const float u = dot3(tvec, pvec) * inv;
+                            const float v = dot3(d, qvec) * inv;
+                            const float t = te * inv;
+                            const bool hit = (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
+                                             (t > tmin && t < tmax);
+                            got |= hit ? (1u << k) : 0u;
+                        }
+                    }
+                }
+                if (got & ~have) atomicOr(&s_mask[pix], got);
+                continue;
+            }
+            if (nq == 0u) break;
+            // ---------------- node step: pops n, pushes <= 4n node items (and <= 4n leaf items, lq < 64 here)
+            uint32_t n = nq < 64u ? nq : 64u;
+            {
+                const uint32_t room = (uint32_t)SP_NQ - KQ_GUARD - (nq < (uint32_t)SP_NQ - KQ_GUARD ? nq : (uint32_t)SP_NQ - KQ_GUARD);
+                const uint32_t fit = room / 3u;
+                if (n > fit) n = fit ? fit : 1u;
+            }
+            nq -= n;
+            bool h0 = false, h1 = false, h2 = false, h3 = false;
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, pix = 0;
+            if ((uint32_t)lane < n) {
+                const uint32_t item = s_nq[nq + (uint32_t)lane];
+                pix = item >> KQ_NODE_BITS;
+                if ((s_mask[pix] & full) != full) {
+                    const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
+                    const float4* np = (const float4*)(node_base + ((size_t)node << 6));
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    const float4 o = s_org[pix];
+                    const uint32_t eb = f2u(q0.w);
+                    const float sx = u2f((eb & 0xffu) << 23), sy = u2f(((eb >> 8) & 0xffu) << 23), sz = u2f(((eb >> 16) & 0xffu) << 23);
+                    // plane - origin per axis: fma(q, s, node origin - ray origin)
+                    const float bx = q0.x - o.x, by = q0.y - o.y, bz = q0.z - o.z;
+                    const uint32_t nx4 = posx ? f2u(q1.x) : f2u(q1.w), fx4 = posx ? f2u(q1.w) : f2u(q1.x);
+                    const uint32_t ny4 = posy ? f2u(q1.y) : f2u(q2.x), fy4 = posy ? f2u(q2.x) : f2u(q1.y);
+                    const uint32_t nz4 = posz ? f2u(q1.z) : f2u(q2.y), fz4 = posz ? f2u(q2.y) : f2u(q1.z);
+                    r0 = f2u(q3.x); r1 = f2u(q3.y); r2 = f2u(q3.z); r3 = f2u(q3.w);
+                    // entry: the smallest near-plane distance any direction can have; exit: the largest far-plane one
+#define VKR_PKT_AXIS(OK, NQW, FQW, C, S, B, IL, IH, TN, TF)                                                         \
+    if (OK) {                                                                                                       \
+        const float an = fma_(ubyte_f(NQW, C), S, B), af = fma_(ubyte_f(FQW, C), S, B);                             \
+        TN = __builtin_fmaxf(TN, __builtin_fminf(an * IL, an * IH));                                                \
+        TF = __builtin_fminf(TF, __builtin_fmaxf(af * IL, af * IH));                                                \
+    } else {                                                                                                        \
+        /* directions straddle zero on this axis: only "origin outside the slab on both sides" could cull */       \
+    }
+#define VKR_PKT_SLAB(HC, C)                                                                                         \
+    {                                                                                                               \
+        float tn = -3.0e38f, tf = 3.0e38f;                                                                          \
+        VKR_PKT_AXIS(okx, nx4, fx4, C, sx, bx, ilx, ihx, tn, tf)                                                    \
+        VKR_PKT_AXIS(oky, ny4, fy4, C, sy, by, ily, ihy, tn, tf)                                                    \
+        VKR_PKT_AXIS(okz, nz4, fz4, C, sz, bz, ilz, ihz, tn, tf)                                                    \
+        tn = __builtin_fmaxf(tn - __builtin_fabsf(tn) * 1e-6f, tmin);                                               \
+        tf = __builtin_fminf(tf + __builtin_fabsf(tf) * 1e-6f, tb);                                                 \
+        HC = (tn <= tf);                                                             \
+    }
+                    VKR_PKT_SLAB(h0, 0) VKR_PKT_SLAB(h1, 1) VKR_PKT_SLAB(h2, 2) VKR_PKT_SLAB(h3, 3)
+#undef VKR_PKT_SLAB
+#undef VKR_PKT_AXIS
+                    // unused slots are stored inverted (near plane beyond far plane) and fail on any constrained
+                    // axis; with all three axes unconstrained nothing could cull them, so mask them explicitly
+                    h0 = h0 && r0 != VKR_CHILD_NONE; h1 = h1 && r1 != VKR_CHILD_NONE;
+                    h2 = h2 && r2 != VKR_CHILD_NONE; h3 = h3 && r3 != VKR_CHILD_NONE;
+                }
+            }
+#define VKR_APPEND(HC, RC)                                                                                          \
+    {                                                                                                               \
+        const bool isl = (int)RC < 0;                                                                               \
+        const unsigned long long mn = __ballot(HC && !isl), ml = __ballot(HC && isl);                               \
+        if (HC) {                                                                                                   \
+            if (isl) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqp[ix] = (uint16_t)pix; }            \
+            else s_nq[nq + mbcnt64(mn)] = (pix << KQ_NODE_BITS) | RC;                                               \
+        }                                                                                                           \
+        nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
+    }
+            VKR_APPEND(h0, r0) VKR_APPEND(h1, r1) VKR_APPEND(h2, r2) VKR_APPEND(h3, r3)
+#undef VKR_APPEND
+        }
+
+        // ------------------------------------------------------------------ phase 3: per pixel
+        for (int j = 0; j < SP_PIX / 64; ++j) {
+            const uint32_t p = (uint32_t)j * 64u + (uint32_t)lane;
+            const uint32_t i = pix0 + p;
+            const uint32_t m = s_mask[p];
+            if (i < sa.count && !(m & 0x80000000u)) {
+                const float visSum = (float)(n_dirs - (uint32_t)__popc(m & full));   // :252-257, a sum of 0/1 terms
+                if (hard) sa.out[i] = visSum > 0.5f ? 1.0f : 0.2f;                   // :233-235
+                else sa.out[i] = mixf(0.0f, 1.0f, visSum / (float)n_dirs);           // :258-259
+            }
+        }
+    }
+}
+
 static hipError_t shadow_q_launch(vkr_ctx* c, int mode, const ShadowArgs& sa, hipStream_t st)
 {
     hipError_t e;
@@ -475,6 +715,22 @@ hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const
     if (count == 0) return hipSuccess;
     if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
         ShadowArgs sa{wp, ng, valid, count, V3{L[0], L[1], L[2]}, radius, samples, V3{0, 0, 0}, out};
+        if (c->sun_packets) {
+            hipError_t e;
+            if (!c->d_sun_frame.p && (e = c->d_sun_frame.alloc(sizeof(SunFrame))) != hipSuccess) return e;
+            SunFrame* sf = (SunFrame*)c->d_sun_frame.p;
+            k_sun_setup<<<1, 64, 0, st>>>(sa.L, radius, samples, sf);
+            const uint32_t n_chunks = (count + SP_PIX - 1u) / SP_PIX;
+            int per_cu = 0;
+            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) return e;
+            if (per_cu < 1) per_cu = 1;
+            uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
+            if (blocks > n_chunks) blocks = n_chunks;
+            if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(8)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
+            k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, c->d_tile_counter.p);
+            return hipGetLastError();
+        }
         return shadow_q_launch(c, 0, sa, st);
     }
     k_shadow_sun<<<(count + VKR_TRACE_BLOCK - 1) / VKR_TRACE_BLOCK, VKR_TRACE_BLOCK, 0, st>>>(

@@ -116,6 +116,7 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     // experiment switches (development only; defaults are the shipped configuration)
     if (const char* e = getenv("VKR_MORTON_EMC")) c->morton_emc = (e[0] == '1');
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
+    if (const char* e = getenv("VKR_SUN_MODE")) c->sun_packets = (e[0] != 'r');         // "ray" = one queue item per ray
     (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     c->H = desc->height;
     auto bail = [&](int code, const char* what, hipError_t err) {
