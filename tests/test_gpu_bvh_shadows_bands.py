@@ -364,3 +364,37 @@ def test_error_behaviour(torch_mod):
     bad_desc = _capi.CreateDesc(99, 16, 16)
     assert lib.vkr_create(C.byref(bad_desc), C.byref(h)) == _capi.VKR_ERR_INVALID_ARG
     ctx.close()
+
+
+@pytest.mark.parametrize("L,radius,samples", [((0.0, 1.0, 0.0), 0.05, 16), ((1.0, 0.0, 0.0), 0.2, 16), ((0.0, -1.0, 0.0), 0.02, 7),
+                                              ((-0.6, 0.01, 0.8), 0.3, 16), ((0.0, 0.0, 0.0), 0.01, 8), ((0.3, 0.9995, 0.01), 0.01, 12)])
+def test_sun_packet_kernel_direction_edge_cases(torch_mod, oracle_mod, L, radius, samples):
+    """The packet traversal's per-axis interval test: sample directions that straddle zero on one or two axes
+    (sun at the zenith / along an axis, wide discs), the alternative tangent frame (|dir.y| >= 0.999, pbr.frag:239),
+    a downward sun and the zero-length light direction (pbr.frag:219-222) -- every ray equal to the oracle's."""
+    import ctypes as C
+    from vulkanrenderer_amd import FrameState, make_street_scene, camera_path
+    from vulkanrenderer_amd.renderer import _check
+    O = oracle_mod
+    scene = make_street_scene(13, 0.02, "shadow")
+    W, H = 128, 72
+    ctx, rt, gb = _ctx(scene, W, H)
+    osc = O.OracleScene(scene)
+    fs = FrameState(W, H)
+    eye, tgt = camera_path(scene, 1)[0]
+    ubo = fs.update(eye, tgt)
+    depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+    gb.upload(depth, normal, wp, ng, valid)
+    import torch
+    out = torch.zeros((H, W), dtype=torch.float32, device=ctx.device)
+    Lc = (C.c_float * 3)(*L)
+    _check(ctx.handle, ctx.lib.vkr_shadow_sun(ctx.handle, gb.world_pos.data_ptr(), gb.geom_normal.data_ptr(), gb.valid.data_ptr(),
+                                              W * H, Lc, float(radius), float(samples), out.data_ptr(), ctx.stream()),
+           "vkr_shadow_sun")
+    ctx.sync()
+    got = out.cpu().numpy()
+    ref = osc.shadow_sun(wp, ng, valid, np.asarray(L, dtype=np.float32), radius, samples)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    if any(L):
+        assert 0.0 < got[valid > 0].mean() < 1.0 or L[1] < 0
+    ctx.close()
