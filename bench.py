@@ -270,6 +270,12 @@ def main():
                           "ao_mrays_per_s_kernel": ao_rays / K / (trace_ms * 1e-3) / 1e6,
                           "atrous_gbs_algorithmic": atrous_bytes / (float(np.mean(t_atrous)) * 1e-3) / 1e9,
                           "first_build_incl_upload_s": first_build_s}
+        # RayTracingContext::updateTopLevelAS on unchanged transforms: re-transform + refit of the resident BVH
+        from vulkanrenderer_amd.renderer import instances_to_array
+        inst_arr = instances_to_array(scene.instance_mesh, scene.instance_transform)
+        out["kernels"]["bvh_refit_ms"] = min(event_time_ms(
+            lambda: ctx.lib.vkr_bvh_refit(ctx.handle, inst_arr, len(scene.instance_mesh), ctx.stream()), None)
+            for _ in range(3))
         if shadows is not None:
             ts = [event_time_ms(lambda: (setattr(shadows, "gb", gbs[i]), shadows.sun(ubos[i])), None) for i in range(Wu, Wu + min(K, 5))]
             out["kernels"]["sun_shadow_ms_full_frame"] = float(np.mean(ts))

@@ -13,11 +13,12 @@
 //   tri (48 B, Morton order so a leaf's triangles are contiguous):
 //       q0 = v0.xyz (mesh | class<<28) | q1 = e1.xyz prim | q2 = e2.xyz flat_id
 //       class: 0 = always an occluder for AO, 1 = never (BLEND), 2 = alpha-test (MASK)
-// Traversal: one ray per lane, "while-while": lanes walk internal nodes until each holds a leaf, then the wave
-// tests leaves together.  Hit children are ordered near-to-far with a 5-exchange network on packed
-// (tnear bits | slot) keys; the deferred ones go to a short stack in LDS ([depth][lane], conflict-free) that
-// spills to per-lane scratch only beyond VKR_LDS_STACK entries.  Entries carry tnear so stale ones are culled
-// at pop time against the current closest hit.
+// Traversal comes in two forms.  The generic traverse<>() below keeps one ray per lane ("while-while": lanes walk
+// internal nodes until each holds a leaf, then the wave tests leaves together; near-to-far order from a 5-exchange
+// network on packed (tnear bits | slot) keys; deferred children on a short LDS stack [depth][lane] that spills to
+// per-lane scratch beyond VKR_LDS_STACK entries, entries carrying tnear so stale ones are culled at pop time).  It
+// serves the G-buffer producer and the fallback kernels.  The hot kernels (k_trace_q, k_shadow_q, k_shadow_sun_pkt)
+// use wave-wide work queues instead; their shared pieces are at the end of this file.
 #pragma once
 #include "device_math.hpp"
 
