@@ -85,16 +85,21 @@ __global__ void k_bounds_init(BvhBounds* b)
 
 __global__ __launch_bounds__(256) void k_bounds(BuildIn in, BvhBounds* out)
 {
-    uint32_t flat = blockIdx.x * 256u + threadIdx.x;
+    // grid-stride: a bounded number of blocks, so the 12 atomics per block do not queue up on 12 addresses
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    if (flat < in.tri_count) {
+    for (uint32_t flat = blockIdx.x * 256u + threadIdx.x; flat < in.tri_count; flat += gridDim.x * 256u) {
         TriW t = emit_tri(in, flat);
-        lo[0] = __builtin_fminf(t.v0.x, __builtin_fminf(t.v1.x, t.v2.x)); hi[0] = __builtin_fmaxf(t.v0.x, __builtin_fmaxf(t.v1.x, t.v2.x));
-        lo[1] = __builtin_fminf(t.v0.y, __builtin_fminf(t.v1.y, t.v2.y)); hi[1] = __builtin_fmaxf(t.v0.y, __builtin_fmaxf(t.v1.y, t.v2.y));
-        lo[2] = __builtin_fminf(t.v0.z, __builtin_fminf(t.v1.z, t.v2.z)); hi[2] = __builtin_fmaxf(t.v0.z, __builtin_fmaxf(t.v1.z, t.v2.z));
+        const float tl[3] = {__builtin_fminf(t.v0.x, __builtin_fminf(t.v1.x, t.v2.x)), __builtin_fminf(t.v0.y, __builtin_fminf(t.v1.y, t.v2.y)),
+                             __builtin_fminf(t.v0.z, __builtin_fminf(t.v1.z, t.v2.z))};
+        const float th[3] = {__builtin_fmaxf(t.v0.x, __builtin_fmaxf(t.v1.x, t.v2.x)), __builtin_fmaxf(t.v0.y, __builtin_fmaxf(t.v1.y, t.v2.y)),
+                             __builtin_fmaxf(t.v0.z, __builtin_fmaxf(t.v1.z, t.v2.z))};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { clo[k] = (lo[k] + hi[k]) * 0.5f; chi[k] = clo[k]; }
+        for (int k = 0; k < 3; ++k) {
+            const float cc = (tl[k] + th[k]) * 0.5f;
+            lo[k] = __builtin_fminf(lo[k], tl[k]); hi[k] = __builtin_fmaxf(hi[k], th[k]);
+            clo[k] = __builtin_fminf(clo[k], cc); chi[k] = __builtin_fmaxf(chi[k], cc);
+        }
     }
     __shared__ float red[4][12];
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -703,7 +708,7 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     const uint32_t nb = (n + 255u) / 256u;
 
     k_bounds_init<<<1, 64, 0, st>>>(c->d_bounds.p);   // also on refit: transforms move the scene, and the
-    k_bounds<<<nb, 256, 0, st>>>(in, c->d_bounds.p);   // conservative padding scales with its extent
+    k_bounds<<<nb < 1024u ? nb : 1024u, 256, 0, st>>>(in, c->d_bounds.p);   // conservative padding scales with its extent
     if (!refit_only) {
         const int emc = c->morton_emc ? 1 : 0;
         const uint32_t mbits = emc ? (c->morton_bits > 15u ? 15u : c->morton_bits) : c->morton_bits;
