@@ -261,6 +261,10 @@ def main():
                            "nodes_per_ray": st.nodes_visited / max(1, ao_rays), "tris_per_ray": st.tris_tested / max(1, ao_rays),
                            "lane_util_node_loop": st.nodes_visited / max(1, 64 * st.wave_node_iters),
                            "lane_util_tri_loop": st.tris_tested / max(1, 64 * st.wave_tri_iters),
+                           # every byte that has to come from HBM at least once: the images + (at most) the whole BVH
+                           "compulsory_bytes_per_launch": 8.0 * px + info.node_count * 64.0 + info.triangle_count * 48.0,
+                           "frac_compulsory": (8.0 * px + info.node_count * 64.0 + info.triangle_count * 48.0)
+                                              / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "achieved = SURVEY 8(d) algorithmic bytes (8 B/px + 64 B per node visit + 48 B per "
                                    "triangle test) / launch time; node and triangle re-reads are served by L1/L2, so the "
                                    "figure can exceed the HBM peak -- the kernel is VALU-issue bound (profiles/), and "

@@ -268,6 +268,56 @@ VKR_API int vkr_gbuffer_primary(vkr_ctx* ctx, const float ubo[VKR_UBO_FLOATS], u
                                 uint16_t* normal_rgba16f, float* world_pos, float* geom_normal, uint8_t* valid,
                                 void* stream);
 
+/* ---------------------------------------------------------------- GPU-driven indirect build */
+
+/* SURVEY 8(f) row 4 (BASELINE configs[2]).  Replaces the per-frame CPU loop FrameManager::prepareSharedOpaqueIndirect
+ * (FrameManager.cpp:118-175) that fills the mapped drawData / indirect-command buffers ScenePass draws from
+ * (vkCmdDrawIndexedIndirect per bucket span).  Independent of the ray-tracing scene: needs no vkr_scene_upload. */
+typedef struct vkr_draw_slot {            /* SharedOpaqueDrawSlot (FrameManager.cpp:99-104)                        */
+    uint32_t node_linear_index, mesh_index, mat_index, double_sided;
+} vkr_draw_slot;
+typedef struct vkr_mesh_draw_info {       /* MeshDrawInfo (GlobalMeshBuffer.h:12-16)                               */
+    uint32_t vertex_offset, first_index, index_count;
+} vkr_mesh_draw_info;
+typedef struct vkr_draw_indexed_indirect_command {   /* VkDrawIndexedIndirectCommand, 20 bytes                    */
+    uint32_t index_count, instance_count, first_index;
+    int32_t vertex_offset;
+    uint32_t first_instance;
+} vkr_draw_indexed_indirect_command;
+typedef struct vkr_bucket_span {          /* SharedOpaqueBucketSpan (FrameManager.cpp:163-171)                     */
+    uint32_t double_sided, mat_index, first_command, draw_count;
+} vkr_bucket_span;
+typedef struct vkr_indirect_desc {        /* all HOST arrays, copied                                               */
+    const int32_t* node_parent;           /* Model::getLinearNodes(): parent's linearIndex or -1; parents first     */
+    const float* node_local;              /* Node::getLocalMatrix() per linear node, 16 floats, GLM column-major    */
+    uint32_t node_count;
+    const vkr_draw_slot* slots;           /* in the collection order of buildSharedDrawSlots (:89-109), BLEND        */
+    uint32_t slot_count;                  /*   meshes already left out (:98); at most 2^24                           */
+    const vkr_mesh_draw_info* mesh_infos; /* GlobalMeshBuffer::getMeshInfos()                                       */
+    uint32_t mesh_count;
+    const float* mesh_bounds;             /* optional: object-space AABB per mesh {min xyz, max xyz}; enables the    */
+                                          /*   frustum test of docs/GPU_DRIVEN_RENDERING_DESIGN.md                   */
+    uint32_t max_draws;                   /* AppConfig::MAX_DRAWS; clamped to >= 1 (FrameManager.cpp:24)            */
+} vkr_indirect_desc;
+/* Replaces FrameManager::buildSharedDrawSlots (FrameManager.cpp:81-116): keeps the slots and applies its
+ * std::stable_sort by (doubleSided, matIndex, meshIndex) (:110-115), once per model. */
+VKR_API int vkr_indirect_upload(vkr_ctx* ctx, const vkr_indirect_desc* desc);
+/* The sorted slots (slot_count entries, HOST): inspection/tests. */
+VKR_API int vkr_indirect_slots_download(vkr_ctx* ctx, vkr_draw_slot* out_slots);
+/* Replaces FrameManager::prepareSharedOpaqueIndirect (:118-175).  model_matrix: GLM column-major.  view_proj: NULL =
+ * the reference as it is (every valid slot draws); non-NULL = additionally drop slots whose mesh AABB, transformed by
+ * the node's world matrix (BoundingBox::Transform, BoundingBox.h:14-39), lies outside the frustum of view_proj
+ * (Frustum::extractPlanes / Intersects, Frustum.h:18-60).  draw_data (DEVICE, capacity x 16 floats) = drawDataMapped,
+ * commands (DEVICE, capacity entries) = indirectMapped; entries past the draw count are left untouched.  capacity is
+ * what the two arrays hold and must be >= min(max_draws, slot_count) (the reference sizes both maxDraws,
+ * FrameManager.cpp:24), else VKR_ERR_INVALID_ARG and nothing is launched. */
+VKR_API int vkr_indirect_prepare(vkr_ctx* ctx, const float model_matrix[16], const float* view_proj, float* draw_data,
+                                 vkr_draw_indexed_indirect_command* commands, uint32_t capacity, void* stream);
+/* sharedOpaqueDrawCount and sharedOpaqueBucketSpans of the last prepare (HOST outputs; synchronises `stream`).
+ * *span_count is the number of spans produced; at most span_capacity are written. */
+VKR_API int vkr_indirect_result(vkr_ctx* ctx, uint32_t* draw_count, vkr_bucket_span* spans, uint32_t span_capacity,
+                                uint32_t* span_count, void* stream);
+
 /* ---------------------------------------------------------------- counters -------------- */
 
 typedef struct vkr_trace_stats {

@@ -242,6 +242,61 @@ def instances_from_nodes(parents, locals_, first_instance, instance_count, model
     return out
 
 
+SLOT_DTYPE = np.dtype([("node_linear_index", "<u4"), ("mesh_index", "<u4"), ("mat_index", "<u4"), ("double_sided", "<u4")])
+MESH_INFO_DTYPE = np.dtype([("vertex_offset", "<u4"), ("first_index", "<u4"), ("index_count", "<u4")])
+DRAW_CMD_DTYPE = np.dtype([("index_count", "<u4"), ("instance_count", "<u4"), ("first_index", "<u4"),
+                           ("vertex_offset", "<i4"), ("first_instance", "<u4")])
+SPAN_DTYPE = np.dtype([("double_sided", "<u4"), ("mat_index", "<u4"), ("first_command", "<u4"), ("draw_count", "<u4")])
+
+
+def sort_draw_slots(slots):
+    """The std::stable_sort of FrameManager::buildSharedDrawSlots (FrameManager.cpp:110-115)."""
+    L = lib()
+    s = np.array(slots, dtype=SLOT_DTYPE, copy=True)
+    L.orc_sort_draw_slots.restype = None
+    L.orc_sort_draw_slots.argtypes = [C.c_void_p, C.c_uint32]
+    L.orc_sort_draw_slots(s.ctypes.data if len(s) else None, len(s))
+    return s
+
+
+def frustum_planes(view_proj):
+    L = lib()
+    m = _f32(np.asarray(view_proj).reshape(16))
+    out = np.zeros(24, dtype=np.float32)
+    L.orc_frustum_planes.restype = None
+    L.orc_frustum_planes.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_frustum_planes(_p(m), _p(out))
+    return out.reshape(6, 4)
+
+
+def prepare_indirect(node_parent, node_local, sorted_slots, mesh_infos, model, max_draws, view_proj=None, mesh_bounds=None):
+    """FrameManager::prepareSharedOpaqueIndirect (FrameManager.cpp:118-175); returns
+    (draw_count, draw_data[n,16], commands[n], spans)."""
+    L = lib()
+    par = np.ascontiguousarray(node_parent, dtype=np.int32)
+    loc = _f32(np.asarray(node_local, dtype=np.float32).reshape(-1, 16))
+    sl = np.ascontiguousarray(sorted_slots, dtype=SLOT_DTYPE)
+    mi = np.ascontiguousarray(mesh_infos, dtype=MESH_INFO_DTYPE)
+    m = _f32(np.asarray(model).reshape(16))
+    md = max(1, int(max_draws))
+    dd = np.zeros((md, 16), dtype=np.float32)
+    cm = np.zeros(md, dtype=DRAW_CMD_DTYPE)
+    cap = max(1, len(sl))
+    sp = np.zeros(cap, dtype=SPAN_DTYPE)
+    vp = None if view_proj is None else _f32(np.asarray(view_proj).reshape(16))
+    mb = None if mesh_bounds is None else _f32(np.asarray(mesh_bounds, dtype=np.float32).reshape(-1, 6))
+    ns = C.c_uint32(0)
+    L.orc_prepare_indirect.restype = C.c_uint32
+    L.orc_prepare_indirect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                       C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_uint32, C.POINTER(C.c_uint32)]
+    n = L.orc_prepare_indirect(par.ctypes.data if len(par) else None, _p(loc) if len(par) else None, len(par),
+                               sl.ctypes.data if len(sl) else None, len(sl), mi.ctypes.data if len(mi) else None, len(mi),
+                               _p(m), int(max_draws), _p(vp) if vp is not None else None,
+                               _p(mb) if mb is not None else None, _p(dd), cm.ctypes.data, sp.ctypes.data, cap, C.byref(ns))
+    return int(n), dd[:n], cm[:n], sp[:ns.value]
+
+
 def atrous(ubo, step, src, depth, normal, y0=0, y1=None):
     H, W = depth.shape
     out = np.zeros((H, W), dtype=np.uint16)

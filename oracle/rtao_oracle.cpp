@@ -36,6 +36,7 @@
 #include <math.h>
 #include <algorithm>
 #include <atomic>
+#include <map>
 #include <vector>
 
 #ifdef _OPENMP
@@ -1155,6 +1156,117 @@ void orc_instances_from_nodes(const orc_node* nodes, uint32_t node_count, const 
                 for (int c = 0; c < 4; ++c) o[r * 4 + c] = m[c * 4 + r];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GPU-driven indirect build.  FrameManager::buildSharedDrawSlots (FrameManager.cpp:81-116) and
+// FrameManager::prepareSharedOpaqueIndirect (:118-175) restated with the same containers (std::stable_sort,
+// std::map<pair<bool,uint32_t>, vector>), plus the documented next step of docs/GPU_DRIVEN_RENDERING_DESIGN.md --
+// a frustum test of the mesh's transformed AABB (Frustum.h:18-60, BoundingBox.h:14-39) -- as an optional filter.
+// ---------------------------------------------------------------------------------------------------------------
+struct orc_draw_slot { uint32_t node_linear_index, mesh_index, mat_index, double_sided; };
+struct orc_mesh_draw_info { uint32_t vertex_offset, first_index, index_count; };      // GlobalMeshBuffer.h:12-16
+struct orc_draw_cmd { uint32_t index_count, instance_count, first_index; int32_t vertex_offset; uint32_t first_instance; };
+struct orc_bucket_span { uint32_t double_sided, mat_index, first_command, draw_count; };
+
+// the sort of buildSharedDrawSlots (:108-115)
+void orc_sort_draw_slots(orc_draw_slot* slots, uint32_t count)
+{
+    std::stable_sort(slots, slots + count, [](const orc_draw_slot& a, const orc_draw_slot& b) {
+        if ((a.double_sided != 0) != (b.double_sided != 0)) return (a.double_sided != 0) < (b.double_sided != 0);
+        if (a.mat_index != b.mat_index) return a.mat_index < b.mat_index;
+        return a.mesh_index < b.mesh_index;
+    });
+}
+
+// Frustum::extractPlanes (Frustum.h:46-60); m = GLM column-major view-projection
+void orc_frustum_planes(const float* m, float* planes /* 6 x 4 */)
+{
+    auto M = [&](int c, int r) { return m[c * 4 + r]; };
+    const int row[6] = {0, 0, 1, 1, 2, 2};
+    const float sg[6] = {1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f};
+    for (int p = 0; p < 6; ++p) {
+        float* o = planes + 4 * p;
+        for (int c = 0; c < 4; ++c) o[c] = (sg[p] > 0.0f) ? M(c, 3) + M(c, row[p]) : M(c, 3) - M(c, row[p]);
+        float len = sqrtf((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]);      // glm::length(vec3)
+        if (len > 1e-6f) { o[0] /= len; o[1] /= len; o[2] /= len; o[3] /= len; }
+    }
+}
+
+// BoundingBox::Transform (BoundingBox.h:14-39) then Frustum::Intersects (Frustum.h:18-44)
+static bool box_in_frustum(const float* world, const float* bmin, const float* bmax, const float* planes)
+{
+    float nmin[3] = {1e30f, 1e30f, 1e30f}, nmax[3] = {-1e30f, -1e30f, -1e30f};
+    for (int i = 0; i < 8; ++i) {
+        const float cx = (i & 1) ? bmax[0] : bmin[0], cy = (i & 2) ? bmax[1] : bmin[1], cz = (i & 4) ? bmax[2] : bmin[2];
+        for (int r = 0; r < 3; ++r) {
+            // glm mat4 * vec4: (m[0]*x + m[1]*y) + (m[2]*z + m[3]*w), w = 1
+            const float p = (world[0 * 4 + r] * cx + world[1 * 4 + r] * cy) + (world[2 * 4 + r] * cz + world[3 * 4 + r] * 1.0f);
+            nmin[r] = p < nmin[r] ? p : nmin[r];            // glm::min(newMin, p): (y < x) ? y : x
+            nmax[r] = nmax[r] < p ? p : nmax[r];            // glm::max(newMax, p): (x < y) ? y : x
+        }
+    }
+    for (int k = 0; k < 6; ++k) {
+        const float* pl = planes + 4 * k;
+        const float vx = pl[0] >= 0.0f ? nmax[0] : nmin[0], vy = pl[1] >= 0.0f ? nmax[1] : nmin[1], vz = pl[2] >= 0.0f ? nmax[2] : nmin[2];
+        if (((pl[0] * vx + pl[1] * vy) + pl[2] * vz) + pl[3] < 0.0f) return false;
+    }
+    return true;
+}
+
+// prepareSharedOpaqueIndirect (:118-175).  nodes: linear nodes (parent linear index or -1, local matrix); slots already
+// sorted; view_proj / mesh_bounds (6 floats per mesh) may be NULL (= the reference as it is: no culling).
+// Outputs sized max_draws (draw_data 16 floats each, commands) and span_capacity; returns the draw count,
+// *span_count = number of bucket spans.
+uint32_t orc_prepare_indirect(const int32_t* node_parent, const float* node_local, uint32_t node_count,
+                              const orc_draw_slot* slots, uint32_t slot_count, const orc_mesh_draw_info* infos,
+                              uint32_t mesh_count, const float* model, uint32_t max_draws_in, const float* view_proj,
+                              const float* mesh_bounds, float* draw_data, orc_draw_cmd* commands, orc_bucket_span* spans,
+                              uint32_t span_capacity, uint32_t* span_count)
+{
+    const uint32_t maxDraws = max_draws_in < 1u ? 1u : max_draws_in;            // FrameManager.cpp:24
+    std::vector<float> world((size_t)node_count * 16);
+    for (uint32_t n = 0; n < node_count; ++n) {                                  // :121-126
+        const float* parentWorld = node_parent[n] >= 0 ? &world[(size_t)node_parent[n] * 16] : model;
+        glm_mul_m4(parentWorld, node_local + (size_t)n * 16, &world[(size_t)n * 16]);
+    }
+    float planes[24];
+    if (view_proj) orc_frustum_planes(view_proj, planes);
+    std::map<std::pair<bool, uint32_t>, std::vector<orc_draw_cmd>> buckets;      // :135-136
+    uint32_t drawId = 0;
+    for (uint32_t i = 0; i < slot_count; ++i) {                                  // :138-152
+        const orc_draw_slot& slot = slots[i];
+        if (drawId >= maxDraws) break;
+        if (slot.node_linear_index >= node_count || slot.mesh_index >= mesh_count) continue;
+        if (view_proj && mesh_bounds &&
+            !box_in_frustum(&world[(size_t)slot.node_linear_index * 16], mesh_bounds + 6 * (size_t)slot.mesh_index,
+                            mesh_bounds + 6 * (size_t)slot.mesh_index + 3, planes))
+            continue;
+        memcpy(draw_data + (size_t)drawId * 16, &world[(size_t)slot.node_linear_index * 16], 64);
+        const orc_mesh_draw_info& info = infos[slot.mesh_index];
+        orc_draw_cmd cmd;
+        cmd.index_count = info.index_count; cmd.instance_count = 1; cmd.first_index = info.first_index;
+        cmd.vertex_offset = (int32_t)info.vertex_offset; cmd.first_instance = drawId;
+        buckets[{slot.double_sided != 0, slot.mat_index}].push_back(cmd);
+        ++drawId;
+    }
+    size_t indirectOffset = 0;
+    uint32_t ns = 0;
+    for (const auto& kv : buckets) {                                             // :154-172
+        const auto& cmds = kv.second;
+        if (cmds.empty()) continue;
+        const size_t canCopy = (indirectOffset < maxDraws) ? std::min(cmds.size(), (size_t)maxDraws - indirectOffset) : 0u;
+        if (canCopy > 0) memcpy(commands + indirectOffset, cmds.data(), canCopy * sizeof(orc_draw_cmd));
+        orc_bucket_span span;
+        span.double_sided = kv.first.first ? 1u : 0u; span.mat_index = kv.first.second;
+        span.first_command = (uint32_t)indirectOffset;
+        const uint32_t available = (span.first_command < maxDraws) ? (maxDraws - span.first_command) : 0u;
+        span.draw_count = (uint32_t)std::min(cmds.size(), (size_t)available);
+        if (span.draw_count > 0) { if (ns < span_capacity) spans[ns] = span; ++ns; }
+        indirectOffset += cmds.size();
+    }
+    *span_count = ns;
+    return drawId;                                                               // :173
 }
 
 float orc_radical_inverse(uint32_t i) { return radicalInverseVdC(i); }

@@ -45,6 +45,31 @@ class SceneNode(C.Structure):
                 ("instance_count", C.c_uint32)]
 
 
+class DrawSlot(C.Structure):               # SharedOpaqueDrawSlot
+    _fields_ = [("node_linear_index", C.c_uint32), ("mesh_index", C.c_uint32), ("mat_index", C.c_uint32),
+                ("double_sided", C.c_uint32)]
+
+
+class MeshDrawInfo(C.Structure):           # GlobalMeshBuffer.h:12-16
+    _fields_ = [("vertex_offset", C.c_uint32), ("first_index", C.c_uint32), ("index_count", C.c_uint32)]
+
+
+class DrawIndexedIndirectCommand(C.Structure):
+    _fields_ = [("index_count", C.c_uint32), ("instance_count", C.c_uint32), ("first_index", C.c_uint32),
+                ("vertex_offset", C.c_int32), ("first_instance", C.c_uint32)]
+
+
+class BucketSpan(C.Structure):             # SharedOpaqueBucketSpan
+    _fields_ = [("double_sided", C.c_uint32), ("mat_index", C.c_uint32), ("first_command", C.c_uint32),
+                ("draw_count", C.c_uint32)]
+
+
+class IndirectDesc(C.Structure):
+    _fields_ = [("node_parent", C.c_void_p), ("node_local", C.c_void_p), ("node_count", C.c_uint32),
+                ("slots", C.c_void_p), ("slot_count", C.c_uint32), ("mesh_infos", C.c_void_p), ("mesh_count", C.c_uint32),
+                ("mesh_bounds", C.c_void_p), ("max_draws", C.c_uint32)]
+
+
 class BvhInfo(C.Structure):
     _fields_ = [("triangle_count", C.c_uint32), ("node_count", C.c_uint32), ("height", C.c_uint32),
                 ("morton_bits", C.c_uint32), ("binary_height", C.c_uint32), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3)]
@@ -87,6 +112,10 @@ SYMBOLS = {
     "vkr_shadow_sun": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), C.c_float, C.c_float, _P, _P]),
     "vkr_shadow_point": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), _P, _P]),
     "vkr_gbuffer_primary": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P]),
+    "vkr_indirect_upload": (C.c_int, [_P, C.POINTER(IndirectDesc)]),
+    "vkr_indirect_slots_download": (C.c_int, [_P, _P]),
+    "vkr_indirect_prepare": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, _P, C.c_uint32, _P]),
+    "vkr_indirect_result": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_uint32, C.POINTER(C.c_uint32), _P]),
     "vkr_trace_stats_enable": (C.c_int, [_P, C.c_int]),
     "vkr_trace_stats_get": (C.c_int, [_P, C.POINTER(TraceStats), C.c_int]),
 }

@@ -1,0 +1,241 @@
+// indirect_build.hip -- SURVEY 8(f) row 4: FrameManager::prepareSharedOpaqueIndirect (FrameManager.cpp:118-175) on
+// the GPU: node world matrices, per-slot validity (+ optional frustum test), stream compaction into
+// DrawIndexedIndirectCommand / per-draw model matrices, bucket spans.  HBM-bound integer/copy work: no MFMA, no LDS
+// beyond the block scans.
+//
+// Why plain compaction reproduces the reference's std::map of buckets: buildSharedDrawSlots (:108-115) leaves the
+// slots sorted by (doubleSided, matIndex, meshIndex), the bucket key is (doubleSided, matIndex) and std::map walks
+// its keys in exactly that order, so the concatenation of the buckets is the slot order itself.  A surviving slot's
+// command therefore lands at index drawId, the rank of the slot among the survivors.
+#include "internal.hpp"
+
+namespace vkr {
+
+constexpr int IB_TILE = 2048;      // slots per scan tile (256 threads x 8)
+
+struct DrawSlotDev { uint32_t node, mesh, mat, ds; };
+struct MeshInfoDev { uint32_t vertex_offset, first_index, index_count; };
+struct DrawCmdDev { uint32_t index_count, instance_count, first_index; int32_t vertex_offset; uint32_t first_instance; };
+struct SpanDev { uint32_t ds, mat, first, count; };
+struct Planes { float p[24]; };
+struct Mat16 { float m[16]; };
+
+VKR_DI void glm_mul_m4_ib(const float* A, const float* B, float* R)   // GLM scalar mat4 product, see bvh_build.hip
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc = A[0 * 4 + r] * B[j * 4 + 0];
+            acc = acc + A[1 * 4 + r] * B[j * 4 + 1];
+            acc = acc + A[2 * 4 + r] * B[j * 4 + 2];
+            acc = acc + A[3 * 4 + r] * B[j * 4 + 3];
+            R[j * 4 + r] = acc;
+        }
+}
+
+// sharedNodeWorldMatrices[n] = parentWorld * local (:121-126).  One thread per node climbs to its root and multiplies
+// back down in the reference's association; depth is bounded by VKR_GRAPH_MAX_DEPTH (checked on upload).
+__global__ __launch_bounds__(256) void k_ib_world(const int32_t* parent, const float4* local, uint32_t n_nodes, Mat16 model,
+                                                  float4* world)
+{
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= n_nodes) return;
+    int chain[VKR_GRAPH_MAX_DEPTH];
+    int depth = 0;
+    for (int a = (int)n; a >= 0 && depth < VKR_GRAPH_MAX_DEPTH; a = parent[a]) chain[depth++] = a;
+    float w[16], nx[16], l[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = model.m[k];
+    for (int d = depth - 1; d >= 0; --d) {
+        const float4* lp = local + (size_t)chain[d] * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { float4 v = lp[c]; l[4 * c] = v.x; l[4 * c + 1] = v.y; l[4 * c + 2] = v.z; l[4 * c + 3] = v.w; }
+        glm_mul_m4_ib(w, l, nx);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = nx[k];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) world[(size_t)n * 4 + c] = make_float4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+}
+
+// BoundingBox::Transform (BoundingBox.h:14-39) + Frustum::Intersects (Frustum.h:18-44)
+VKR_DI bool box_in_frustum(const float4* wm, const float* b, const Planes& pl)
+{
+    const float4 c0 = wm[0], c1 = wm[1], c2 = wm[2], c3 = wm[3];
+    const float m0[3] = {c0.x, c0.y, c0.z}, m1[3] = {c1.x, c1.y, c1.z}, m2[3] = {c2.x, c2.y, c2.z}, m3[3] = {c3.x, c3.y, c3.z};
+    float nmin[3] = {1e30f, 1e30f, 1e30f}, nmax[3] = {-1e30f, -1e30f, -1e30f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float cx = (i & 1) ? b[3] : b[0], cy = (i & 2) ? b[4] : b[1], cz = (i & 4) ? b[5] : b[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float p = (m0[r] * cx + m1[r] * cy) + (m2[r] * cz + m3[r] * 1.0f);   // glm mat4 * vec4
+            nmin[r] = p < nmin[r] ? p : nmin[r];
+            nmax[r] = nmax[r] < p ? p : nmax[r];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float* q = pl.p + 4 * k;
+        const float vx = q[0] >= 0.0f ? nmax[0] : nmin[0], vy = q[1] >= 0.0f ? nmax[1] : nmin[1], vz = q[2] >= 0.0f ? nmax[2] : nmin[2];
+        if (((q[0] * vx + q[1] * vy) + q[2] * vz) + q[3] < 0.0f) return false;
+    }
+    return true;
+}
+
+VKR_DI bool slot_survives(const DrawSlotDev& s, uint32_t n_nodes, uint32_t n_meshes, const float4* world, const float* bounds,
+                          bool cull, const Planes& pl)
+{
+    if (s.node >= n_nodes || s.mesh >= n_meshes) return false;                    // :140
+    if (cull && !box_in_frustum(world + (size_t)s.node * 4, bounds + 6 * (size_t)s.mesh, pl)) return false;
+    return true;
+}
+
+// pass 1: survivors per tile
+__global__ __launch_bounds__(256) void k_ib_count(const DrawSlotDev* slots, uint32_t n_slots, uint32_t n_nodes, uint32_t n_meshes,
+                                                  const float4* world, const float* bounds, int cull, Planes pl,
+                                                  uint32_t* tile_count, uint8_t* flags)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int k = 0; k < IB_TILE / 256; ++k) {
+        const uint32_t i = blockIdx.x * IB_TILE + k * 256 + threadIdx.x;
+        bool ok = false;
+        if (i < n_slots) {
+            ok = slot_survives(slots[i], n_nodes, n_meshes, world, bounds, cull != 0, pl);
+            flags[i] = ok ? 1 : 0;
+        }
+        mine += (uint32_t)__popcll(__ballot(ok)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);
+    }
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = s_cnt;
+}
+
+// pass 2: exclusive scan of the tile counts (one block; tiles <= 2^24 / 2048 = 8192)
+__global__ __launch_bounds__(1024) void k_ib_scan_tiles(uint32_t* tile_count, uint32_t n_tiles, uint32_t* total)
+{
+    __shared__ uint32_t s_part[1024];
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per, e = (b + per < n_tiles) ? b + per : n_tiles;
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; ++i) sum += tile_count[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (threadIdx.x >= (uint32_t)off) ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (uint32_t i = b; i < e; ++i) { uint32_t c = tile_count[i]; tile_count[i] = run; run += c; }
+    if (threadIdx.x == 1023) *total = s_part[1023];
+}
+
+// pass 3: rank the survivors inside each tile and emit (:141-151).  keys[drawId] = doubleSided << 31 | matIndex.
+__global__ __launch_bounds__(256) void k_ib_emit(const DrawSlotDev* slots, uint32_t n_slots, const uint8_t* flags,
+                                                 const uint32_t* tile_base, const MeshInfoDev* infos, const float4* world,
+                                                 uint32_t max_draws, float4* draw_data, DrawCmdDev* commands, uint64_t* keys)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_run;
+    if (threadIdx.x == 0) s_run = tile_base[blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < IB_TILE / 256; ++k) {
+        const uint32_t i = blockIdx.x * IB_TILE + k * 256 + threadIdx.x;
+        const bool ok = (i < n_slots) && flags[i];
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t base = s_run;
+        for (int w = 0; w < wave; ++w) base += s_wave[w];
+        const uint32_t id = base + mbcnt64(m);
+        if (ok && id < max_draws) {                                               // :139 "break" = every later id is >= too
+            const DrawSlotDev s = slots[i];
+            const float4* wm = world + (size_t)s.node * 4;
+            float4* dd = draw_data + (size_t)id * 4;
+            dd[0] = wm[0]; dd[1] = wm[1]; dd[2] = wm[2]; dd[3] = wm[3];           // :141
+            const MeshInfoDev info = infos[s.mesh];
+            DrawCmdDev c;
+            c.index_count = info.index_count; c.instance_count = 1; c.first_index = info.first_index;
+            c.vertex_offset = (int32_t)info.vertex_offset; c.first_instance = id; // :143-148
+            commands[id] = c;
+            keys[id] = ((uint64_t)(s.ds ? 1u : 0u) << 32) | s.mat;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+}
+
+// bucket spans (:154-172): a span starts wherever the key changes along the emitted commands
+__global__ __launch_bounds__(256) void k_ib_span_heads(const uint64_t* keys, const uint32_t* total, uint32_t max_draws,
+                                                       uint32_t* span_count, uint32_t* head_pos, uint32_t span_capacity)
+{
+    const uint32_t n = *total < max_draws ? *total : max_draws;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || keys[i] != keys[i - 1]) {
+        const uint32_t s = atomicAdd(span_count, 1u);
+        if (s < span_capacity) head_pos[s] = i;
+    }
+}
+
+// spans are few (<= 2 x materials): one block orders the head positions and closes the ranges
+__global__ __launch_bounds__(256) void k_ib_span_emit(const uint64_t* keys, const uint32_t* total, uint32_t max_draws,
+                                                      const uint32_t* span_count, uint32_t* head_pos, uint32_t span_capacity,
+                                                      SpanDev* spans)
+{
+    const uint32_t n = *total < max_draws ? *total : max_draws;
+    uint32_t ns = *span_count < span_capacity ? *span_count : span_capacity;
+    // rank sort of the head positions (distinct values), O(ns^2 / 256) -- ns is at most a few hundred
+    for (uint32_t a = threadIdx.x; a < ns; a += 256u) {
+        const uint32_t pos = head_pos[a];
+        uint32_t rank = 0, next = n;
+        for (uint32_t b = 0; b < ns; ++b) {
+            const uint32_t q = head_pos[b];
+            rank += (q < pos) ? 1u : 0u;
+            if (q > pos && q < next) next = q;
+        }
+        const uint64_t key = keys[pos];
+        SpanDev sp;
+        sp.ds = (uint32_t)(key >> 32); sp.mat = (uint32_t)key; sp.first = pos; sp.count = next - pos;
+        spans[rank] = sp;
+    }
+}
+
+#define IB_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t indirect_prepare_launch(vkr_ctx* c, const float model[16], const float* planes24, float4* draw_data,
+                                   void* commands, hipStream_t st)
+{
+    const uint32_t ns = c->ib_slot_count, nn = c->ib_node_count;
+    Mat16 m;
+    for (int k = 0; k < 16; ++k) m.m[k] = model[k];
+    Planes pl;
+    for (int k = 0; k < 24; ++k) pl.p[k] = planes24 ? planes24[k] : 0.0f;
+    IB_TRY(hipMemsetAsync(c->d_ib_counters.p, 0, 8, st));      // [0] total survivors, [1] span count
+    if (nn) k_ib_world<<<(nn + 255u) / 256u, 256, 0, st>>>(c->d_ib_parent.p, c->d_ib_local.p, nn, m, c->d_ib_world.p);
+    if (ns == 0) return hipGetLastError();
+    const uint32_t tiles = (ns + IB_TILE - 1) / IB_TILE;
+    const int cull = (planes24 && c->d_ib_bounds.p) ? 1 : 0;
+    k_ib_count<<<tiles, 256, 0, st>>>((const DrawSlotDev*)c->d_ib_slots.p, ns, nn, c->ib_mesh_count, c->d_ib_world.p,
+                                      c->d_ib_bounds.p, cull, pl, c->d_ib_tile.p, c->d_ib_flags.p);
+    k_ib_scan_tiles<<<1, 1024, 0, st>>>(c->d_ib_tile.p, tiles, c->d_ib_counters.p);
+    k_ib_emit<<<tiles, 256, 0, st>>>((const DrawSlotDev*)c->d_ib_slots.p, ns, c->d_ib_flags.p, c->d_ib_tile.p,
+                                     (const MeshInfoDev*)c->d_ib_infos.p, c->d_ib_world.p, c->ib_max_draws, draw_data,
+                                     (DrawCmdDev*)commands, c->d_ib_keys.p);
+    const uint32_t cap = ns < c->ib_max_draws ? ns : c->ib_max_draws;
+    k_ib_span_heads<<<(cap + 255u) / 256u, 256, 0, st>>>(c->d_ib_keys.p, c->d_ib_counters.p, c->ib_max_draws,
+                                                         c->d_ib_counters.p + 1, c->d_ib_heads.p, c->ib_span_capacity);
+    k_ib_span_emit<<<1, 256, 0, st>>>(c->d_ib_keys.p, c->d_ib_counters.p, c->ib_max_draws, c->d_ib_counters.p + 1,
+                                      c->d_ib_heads.p, c->ib_span_capacity, (SpanDev*)c->d_ib_spans.p);
+    return hipGetLastError();
+}
+
+}  // namespace vkr

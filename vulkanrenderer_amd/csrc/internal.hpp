@@ -94,6 +94,20 @@ struct vkr_ctx {
     bool has_cached_model = false;
     float cached_model[16] = {0};
 
+    // ---- GPU-driven indirect build (FrameManager::buildSharedDrawSlots / prepareSharedOpaqueIndirect)
+    bool has_indirect = false;
+    uint32_t ib_node_count = 0, ib_slot_count = 0, ib_mesh_count = 0, ib_max_draws = 1, ib_span_capacity = 1;
+    vkr::DevBuf<int32_t> d_ib_parent;
+    vkr::DevBuf<float4> d_ib_local, d_ib_world;   // 4 x float4 per linear node
+    vkr::DevBuf<uint4> d_ib_slots;                // sorted SharedOpaqueDrawSlot
+    vkr::DevBuf<uint32_t> d_ib_infos;             // MeshDrawInfo, 3 words per mesh
+    vkr::DevBuf<float> d_ib_bounds;               // optional mesh AABBs, 6 floats per mesh
+    vkr::DevBuf<uint8_t> d_ib_flags;
+    vkr::DevBuf<uint32_t> d_ib_tile, d_ib_counters, d_ib_heads;
+    vkr::DevBuf<uint64_t> d_ib_keys;
+    vkr::DevBuf<uint4> d_ib_spans;
+    std::vector<uint4> h_ib_slots;
+
     // ---- BVH
     bool has_bvh = false;
     uint32_t morton_bits = 21;
@@ -162,6 +176,9 @@ inline SceneDev scene_dev(const vkr_ctx* c)
 hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st);
 hipError_t bvh_wide_launch(vkr_ctx* c, uint32_t bin_height, hipStream_t st);
 hipError_t instances_from_nodes_launch(vkr_ctx* c, const float model[16], hipStream_t st);
+// indirect_build.hip
+hipError_t indirect_prepare_launch(vkr_ctx* c, const float model[16], const float* planes24, float4* draw_data,
+                                   void* commands, hipStream_t st);
 // rtao_kernels.hip
 hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,
                              uint16_t* hist_curr, uint32_t* hit_mask, int y0, int y1, hipStream_t st);

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "internal.hpp"
 
 using namespace vkr;
@@ -155,6 +157,11 @@ void vkr_destroy(vkr_ctx* c)
     for (int i = 0; i < 2; ++i) { c->d_keys[i].release(); c->d_vals[i].release(); c->d_hist_img[i].release(); c->d_ping[i].release(); }
     c->d_hist.release(); c->d_digit_totals.release(); c->d_bounds.release(); c->d_height.release();
     c->d_nz.release(); c->d_stats.release(); c->d_raybuf.release();
+    c->d_normals.release(); c->d_mesh_has_normals.release(); c->d_graph.release(); c->d_tile_counter.release();
+    c->d_sun_frame.release();
+    c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
+    c->d_ib_infos.release(); c->d_ib_bounds.release(); c->d_ib_flags.release(); c->d_ib_tile.release();
+    c->d_ib_counters.release(); c->d_ib_heads.release(); c->d_ib_keys.release(); c->d_ib_spans.release();
     delete c;
 }
 
@@ -473,6 +480,128 @@ int vkr_instances_download(vkr_ctx* c, float* out)
     HIP_OR_FAIL(c, hipDeviceSynchronize());
     if (c->instance_count)
         HIP_OR_FAIL(c, hipMemcpy(out, c->d_inst_xf.p, (size_t)c->instance_count * 48, hipMemcpyDeviceToHost));
+    return VKR_OK;
+}
+
+// ---------------------------------------------------------------- GPU-driven indirect build
+
+int vkr_indirect_upload(vkr_ctx* c, const vkr_indirect_desc* d)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!d) return fail(c, VKR_ERR_INVALID_ARG, "desc is NULL");
+    if ((d->node_count && (!d->node_parent || !d->node_local)) || (d->slot_count && !d->slots) ||
+        (d->mesh_count && !d->mesh_infos))
+        return fail(c, VKR_ERR_INVALID_ARG, "indirect desc: NULL array with non-zero count");
+    if (d->slot_count > (1u << 24)) return fail(c, VKR_ERR_LIMIT, "more than 2^24 draw slots");
+    if (int rc = set_device(c)) return rc;
+    c->has_indirect = false;
+    std::vector<int> depth(d->node_count, 0);
+    for (uint32_t i = 0; i < d->node_count; ++i) {   // FrameManager.cpp:122-126 reads the parent's matrix: it must be earlier
+        const int32_t p = d->node_parent[i];
+        if (p >= (int32_t)i || p < -1)
+            return fail(c, VKR_ERR_INVALID_ARG, "linear node %u: parent %d must precede it", i, p);
+        depth[i] = p < 0 ? 1 : depth[p] + 1;
+        if (depth[i] > VKR_GRAPH_MAX_DEPTH) return fail(c, VKR_ERR_LIMIT, "linear node %u: hierarchy deeper than %d", i, VKR_GRAPH_MAX_DEPTH);
+    }
+    // the sort of buildSharedDrawSlots (FrameManager.cpp:110-115), once per model like the reference
+    c->h_ib_slots.resize(d->slot_count);
+    for (uint32_t i = 0; i < d->slot_count; ++i)
+        c->h_ib_slots[i] = make_uint4(d->slots[i].node_linear_index, d->slots[i].mesh_index, d->slots[i].mat_index,
+                                      d->slots[i].double_sided ? 1u : 0u);
+    std::stable_sort(c->h_ib_slots.begin(), c->h_ib_slots.end(), [](const uint4& a, const uint4& b) {
+        if (a.w != b.w) return a.w < b.w;
+        if (a.z != b.z) return a.z < b.z;
+        return a.y < b.y;
+    });
+    uint32_t keys = 0;
+    for (uint32_t i = 0; i < d->slot_count; ++i)
+        if (i == 0 || c->h_ib_slots[i].w != c->h_ib_slots[i - 1].w || c->h_ib_slots[i].z != c->h_ib_slots[i - 1].z) ++keys;
+    c->ib_node_count = d->node_count; c->ib_slot_count = d->slot_count; c->ib_mesh_count = d->mesh_count;
+    c->ib_max_draws = d->max_draws < 1u ? 1u : d->max_draws;      // std::max(1u, MAX_DRAWS), FrameManager.cpp:24
+    c->ib_span_capacity = keys ? keys : 1u;
+    const uint32_t tiles = (d->slot_count + 2047u) / 2048u;
+    HIP_OR_FAIL(c, c->d_ib_parent.alloc(d->node_count ? d->node_count : 1));
+    HIP_OR_FAIL(c, c->d_ib_local.alloc((size_t)(d->node_count ? d->node_count : 1) * 4));
+    HIP_OR_FAIL(c, c->d_ib_world.alloc((size_t)(d->node_count ? d->node_count : 1) * 4));
+    HIP_OR_FAIL(c, c->d_ib_slots.alloc(d->slot_count ? d->slot_count : 1));
+    HIP_OR_FAIL(c, c->d_ib_infos.alloc((size_t)(d->mesh_count ? d->mesh_count : 1) * 3));
+    HIP_OR_FAIL(c, c->d_ib_flags.alloc(d->slot_count ? d->slot_count : 1));
+    HIP_OR_FAIL(c, c->d_ib_tile.alloc(tiles ? tiles : 1));
+    HIP_OR_FAIL(c, c->d_ib_counters.alloc(2));
+    HIP_OR_FAIL(c, c->d_ib_heads.alloc(c->ib_span_capacity));
+    HIP_OR_FAIL(c, c->d_ib_spans.alloc(c->ib_span_capacity));
+    HIP_OR_FAIL(c, c->d_ib_keys.alloc(d->slot_count ? d->slot_count : 1));
+    HIP_OR_FAIL(c, hipMemset(c->d_ib_counters.p, 0, 8));
+    if (d->node_count) {
+        HIP_OR_FAIL(c, hipMemcpy(c->d_ib_parent.p, d->node_parent, (size_t)d->node_count * 4, hipMemcpyHostToDevice));
+        HIP_OR_FAIL(c, hipMemcpy(c->d_ib_local.p, d->node_local, (size_t)d->node_count * 64, hipMemcpyHostToDevice));
+    }
+    if (d->slot_count) HIP_OR_FAIL(c, hipMemcpy(c->d_ib_slots.p, c->h_ib_slots.data(), (size_t)d->slot_count * 16, hipMemcpyHostToDevice));
+    if (d->mesh_count) HIP_OR_FAIL(c, hipMemcpy(c->d_ib_infos.p, d->mesh_infos, (size_t)d->mesh_count * 12, hipMemcpyHostToDevice));
+    c->d_ib_bounds.release();
+    if (d->mesh_bounds && d->mesh_count) {
+        HIP_OR_FAIL(c, c->d_ib_bounds.alloc((size_t)d->mesh_count * 6));
+        HIP_OR_FAIL(c, hipMemcpy(c->d_ib_bounds.p, d->mesh_bounds, (size_t)d->mesh_count * 24, hipMemcpyHostToDevice));
+    }
+    c->has_indirect = true;
+    return VKR_OK;
+}
+
+int vkr_indirect_slots_download(vkr_ctx* c, vkr_draw_slot* out)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!c->has_indirect) return fail(c, VKR_ERR_STATE, "vkr_indirect_slots_download before vkr_indirect_upload");
+    if (!out && c->ib_slot_count) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
+    for (uint32_t i = 0; i < c->ib_slot_count; ++i) {
+        out[i].node_linear_index = c->h_ib_slots[i].x; out[i].mesh_index = c->h_ib_slots[i].y;
+        out[i].mat_index = c->h_ib_slots[i].z; out[i].double_sided = c->h_ib_slots[i].w;
+    }
+    return VKR_OK;
+}
+
+int vkr_indirect_prepare(vkr_ctx* c, const float model[16], const float* view_proj, float* draw_data,
+                         vkr_draw_indexed_indirect_command* commands, uint32_t capacity, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!c->has_indirect) return fail(c, VKR_ERR_STATE, "vkr_indirect_prepare before vkr_indirect_upload");
+    if (!model || !draw_data || !commands) return fail(c, VKR_ERR_INVALID_ARG, "model, draw_data and commands must be non-NULL");
+    const uint32_t need = c->ib_slot_count < c->ib_max_draws ? c->ib_slot_count : c->ib_max_draws;
+    if (capacity < need)
+        return fail(c, VKR_ERR_INVALID_ARG, "capacity %u of draw_data/commands is below min(max_draws, slot_count) = %u", capacity, need);
+    if (view_proj && !c->d_ib_bounds.p) return fail(c, VKR_ERR_STATE, "frustum culling asked for but no mesh_bounds were uploaded");
+    if (int rc = set_device(c)) return rc;
+    float planes[24];
+    if (view_proj) {   // Frustum::extractPlanes (Frustum.h:46-60), once per frame on the host like the reference would
+        const int row[6] = {0, 0, 1, 1, 2, 2};
+        for (int p = 0; p < 6; ++p) {
+            float* o = planes + 4 * p;
+            for (int k = 0; k < 4; ++k)
+                o[k] = (p & 1) ? view_proj[k * 4 + 3] - view_proj[k * 4 + row[p]] : view_proj[k * 4 + 3] + view_proj[k * 4 + row[p]];
+            const float len = sqrtf((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]);
+            if (len > 1e-6f) { o[0] /= len; o[1] /= len; o[2] /= len; o[3] /= len; }
+        }
+    }
+    HIP_OR_FAIL(c, indirect_prepare_launch(c, model, view_proj ? planes : nullptr, (float4*)draw_data, commands, (hipStream_t)stream));
+    return VKR_OK;
+}
+
+int vkr_indirect_result(vkr_ctx* c, uint32_t* draw_count, vkr_bucket_span* spans, uint32_t span_capacity, uint32_t* span_count,
+                        void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!c->has_indirect) return fail(c, VKR_ERR_STATE, "vkr_indirect_result before vkr_indirect_upload");
+    if (int rc = set_device(c)) return rc;
+    HIP_OR_FAIL(c, hipStreamSynchronize((hipStream_t)stream));
+    uint32_t cnt[2] = {0, 0};
+    HIP_OR_FAIL(c, hipMemcpy(cnt, c->d_ib_counters.p, 8, hipMemcpyDeviceToHost));
+    const uint32_t draws = cnt[0] < c->ib_max_draws ? cnt[0] : c->ib_max_draws;
+    const uint32_t ns = cnt[1] < c->ib_span_capacity ? cnt[1] : c->ib_span_capacity;
+    if (draw_count) *draw_count = draws;                      // sharedOpaqueDrawCount, FrameManager.cpp:174
+    if (span_count) *span_count = ns;
+    if (spans && ns) {
+        const uint32_t n = ns < span_capacity ? ns : span_capacity;
+        if (n) HIP_OR_FAIL(c, hipMemcpy(spans, c->d_ib_spans.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    }
     return VKR_OK;
 }
 

@@ -191,6 +191,77 @@ class RayTracingContext:
         return nodes[:info.node_count], tris[:info.triangle_count]
 
 
+SLOT_DTYPE = np.dtype([("node_linear_index", "<u4"), ("mesh_index", "<u4"), ("mat_index", "<u4"), ("double_sided", "<u4")])
+MESH_INFO_DTYPE = np.dtype([("vertex_offset", "<u4"), ("first_index", "<u4"), ("index_count", "<u4")])
+DRAW_CMD_DTYPE = np.dtype([("index_count", "<u4"), ("instance_count", "<u4"), ("first_index", "<u4"),
+                           ("vertex_offset", "<i4"), ("first_instance", "<u4")])
+SPAN_DTYPE = np.dtype([("double_sided", "<u4"), ("mat_index", "<u4"), ("first_command", "<u4"), ("draw_count", "<u4")])
+
+
+class SharedOpaqueIndirect:
+    """FrameManager::buildSharedDrawSlots + prepareSharedOpaqueIndirect (FrameManager.cpp:81-175) on the device:
+    per frame, node world matrices -> drawData (mat4 per draw) + VkDrawIndexedIndirectCommand[] + bucket spans."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.max_draws = 1
+        self.slot_count = 0
+        self.draw_data = None        # torch float32 [max_draws, 16]  (drawDataMapped)
+        self.commands = None         # torch uint8   [max_draws, 20]  (indirectMapped)
+
+    def buildSharedDrawSlots(self, node_parent, node_local, slots, mesh_infos, max_draws: int, mesh_bounds=None):
+        c = self.ctx
+        par = np.ascontiguousarray(node_parent, dtype=np.int32)
+        loc = np.ascontiguousarray(node_local, dtype=np.float32).reshape(-1, 16)
+        sl = np.ascontiguousarray(slots, dtype=SLOT_DTYPE)
+        mi = np.ascontiguousarray(mesh_infos, dtype=MESH_INFO_DTYPE)
+        mb = None if mesh_bounds is None else np.ascontiguousarray(mesh_bounds, dtype=np.float32).reshape(-1, 6)
+        if mb is not None and len(mb) != len(mi):
+            raise ValueError("mesh_bounds needs one AABB per mesh")
+        d = _capi.IndirectDesc(par.ctypes.data if len(par) else None, loc.ctypes.data if len(par) else None, len(par),
+                               sl.ctypes.data if len(sl) else None, len(sl), mi.ctypes.data if len(mi) else None, len(mi),
+                               mb.ctypes.data if mb is not None and len(mb) else None, int(max_draws))
+        _check(c.handle, c.lib.vkr_indirect_upload(c.handle, C.byref(d)), "vkr_indirect_upload")
+        self.max_draws = max(1, int(max_draws))
+        self.slot_count = len(sl)
+        self.draw_data = torch.zeros((self.max_draws, 16), dtype=torch.float32, device=c.device)
+        self.commands = torch.zeros((self.max_draws, 20), dtype=torch.uint8, device=c.device)
+
+    def sortedSlots(self) -> np.ndarray:
+        c = self.ctx
+        out = np.zeros(max(1, self.slot_count), dtype=SLOT_DTYPE)
+        _check(c.handle, c.lib.vkr_indirect_slots_download(c.handle, out.ctypes.data), "vkr_indirect_slots_download")
+        return out[:self.slot_count]
+
+    def prepareSharedOpaqueIndirect(self, model_matrix, view_proj=None):
+        """Enqueue one frame's build on the context's stream (asynchronous)."""
+        c = self.ctx
+        m = (C.c_float * 16)(*[float(x) for x in np.asarray(model_matrix, dtype=np.float32).reshape(16)])
+        vp = None
+        if view_proj is not None:
+            vp = (C.c_float * 16)(*[float(x) for x in np.asarray(view_proj, dtype=np.float32).reshape(16)])
+        _check(c.handle, c.lib.vkr_indirect_prepare(c.handle, m, C.cast(vp, C.c_void_p) if vp is not None else None,
+                                                    self.draw_data.data_ptr(), self.commands.data_ptr(),
+                                                    min(self.draw_data.numel() // 16, self.commands.numel() // 20), c.stream()),
+               "vkr_indirect_prepare")
+
+    def result(self):
+        """(sharedOpaqueDrawCount, sharedOpaqueBucketSpans); synchronises."""
+        c = self.ctx
+        cap = max(1, self.slot_count)
+        spans = np.zeros(cap, dtype=SPAN_DTYPE)
+        dc, sc = C.c_uint32(0), C.c_uint32(0)
+        _check(c.handle, c.lib.vkr_indirect_result(c.handle, C.byref(dc), spans.ctypes.data, cap, C.byref(sc), c.stream()),
+               "vkr_indirect_result")
+        return int(dc.value), spans[:sc.value]
+
+    def download(self):
+        n, spans = self.result()
+        dd = self.draw_data[:n].cpu().numpy()
+        cm = self.commands[:n].cpu().numpy().reshape(-1).view(DRAW_CMD_DTYPE)
+        return n, dd, cm, spans
+
+
 @dataclass
 class RenderStats:            # RenderPass.h:12-36 (only the field this path fills)
     rtaoMs: float = 0.0

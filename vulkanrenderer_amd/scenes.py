@@ -372,6 +372,61 @@ def make_scene_graph(scene: SceneData, seed: int = 1, group_size: int = 6, max_d
             np.asarray(firsts, dtype=np.uint32), np.asarray(counts, dtype=np.uint32))
 
 
+def make_draw_model(n_nodes: int, n_meshes: int, n_materials: int = 64, seed: int = 3, max_depth: int = 8,
+                    invalid_fraction: float = 0.0, extent: float = 60.0):
+    """A synthetic Model for the GPU-driven indirect build (BASELINE configs[2]): linear nodes (parents first, like
+    Model::getLinearNodes), per-node local matrices (rotation about Y, scale, translation), draw slots in the
+    collection order of FrameManager::buildSharedDrawSlots (node order, one slot per (node, meshIndex)), MeshDrawInfo
+    and object-space mesh AABBs.  `invalid_fraction` of the slots get an out-of-range node or mesh index (the
+    `continue` of FrameManager.cpp:140).  Returns a dict of numpy arrays."""
+    rng = np.random.default_rng(seed)
+    parent = np.full(n_nodes, -1, dtype=np.int32)
+    # level by level (parents first): level 0 = roots, every later node hangs under a random node of the level above
+    n_roots = max(1, n_nodes // 64)
+    bounds_lv = np.unique(np.linspace(n_roots, n_nodes, max(1, max_depth - 1) + 1).astype(np.int64)) if n_nodes > n_roots else []
+    prev_lo, prev_hi = 0, min(n_roots, n_nodes)
+    for a, b in zip(bounds_lv[:-1], bounds_lv[1:]):
+        parent[a:b] = rng.integers(prev_lo, prev_hi, b - a)
+        prev_lo, prev_hi = int(a), int(b)
+    ang = rng.uniform(-np.pi, np.pi, n_nodes)
+    sc = rng.uniform(0.6, 1.5, n_nodes)
+    tr = rng.uniform(-extent, extent, (n_nodes, 3)) * np.where(parent[:, None] < 0, 1.0, 0.15)
+    local = np.zeros((n_nodes, 4, 4), dtype=np.float64)      # [col][row]
+    local[:, 0, 0] = np.cos(ang) * sc; local[:, 0, 2] = -np.sin(ang) * sc
+    local[:, 1, 1] = sc
+    local[:, 2, 0] = np.sin(ang) * sc; local[:, 2, 2] = np.cos(ang) * sc
+    local[:, 3, :3] = tr; local[:, 3, 3] = 1.0
+    local = local.reshape(n_nodes, 16).astype(np.float32)
+    # meshes: packed into one global vertex/index buffer
+    idx_count = (rng.integers(4, 4000, n_meshes) * 3).astype(np.uint32)
+    vtx_count = rng.integers(8, 3000, n_meshes).astype(np.uint32)
+    infos = np.zeros(n_meshes, dtype=[("vertex_offset", "<u4"), ("first_index", "<u4"), ("index_count", "<u4")])
+    infos["index_count"] = idx_count
+    infos["first_index"] = np.concatenate([[0], np.cumsum(idx_count[:-1], dtype=np.uint64)]).astype(np.uint32)
+    infos["vertex_offset"] = np.concatenate([[0], np.cumsum(vtx_count[:-1], dtype=np.uint64)]).astype(np.uint32)
+    half = rng.uniform(0.1, 2.5, (n_meshes, 3))
+    cen = rng.uniform(-1.0, 1.0, (n_meshes, 3))
+    bounds = np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
+    mesh_mat = rng.integers(0, n_materials, n_meshes).astype(np.uint32)
+    mat_ds = rng.random(n_materials) < 0.25
+    # slots: ~1 per node on average, node order
+    per_node = rng.choice([0, 1, 1, 1, 2, 3], n_nodes)
+    node_of = np.repeat(np.arange(n_nodes, dtype=np.uint32), per_node)
+    mesh_of = rng.integers(0, n_meshes, len(node_of)).astype(np.uint32)
+    slots = np.zeros(len(node_of), dtype=[("node_linear_index", "<u4"), ("mesh_index", "<u4"), ("mat_index", "<u4"),
+                                          ("double_sided", "<u4")])
+    slots["node_linear_index"] = node_of
+    slots["mesh_index"] = mesh_of
+    slots["mat_index"] = mesh_mat[mesh_of]
+    slots["double_sided"] = mat_ds[mesh_mat[mesh_of]].astype(np.uint32)
+    if invalid_fraction > 0 and len(slots):
+        bad = rng.random(len(slots)) < invalid_fraction
+        which = rng.random(len(slots)) < 0.5
+        slots["node_linear_index"][bad & which] = n_nodes + 7
+        slots["mesh_index"][bad & ~which] = 0xFFFFFFFF
+    return {"node_parent": parent, "node_local": local, "slots": slots, "mesh_infos": infos, "mesh_bounds": bounds}
+
+
 def make_bistro_class(seed: int = 0xB1572026) -> SceneData:
     return make_street_scene(seed, 1.0, "bistro-class")
 
