@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "c0", "c3", "c4"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "c0", "c2", "c3", "c4"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip per-kernel timing / counters")
     return ap.parse_args()
@@ -103,8 +103,82 @@ def log(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - T_START:.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def main_c2(args):
+    """Workload c2 (BASELINE configs[2]): 1M-node synthetic model, per frame world matrices +
+    frustum cull + DrawIndexedIndirectCommand compaction (FrameManager::prepareSharedOpaqueIndirect on the device).
+    Not sharded: N > 1 would be replicas only, so this workload runs at N = 1."""
+    from vulkanrenderer_amd import Context, SharedOpaqueIndirect, make_draw_model
+    from vulkanrenderer_amd.scenes import look_at_rh, perspective_rh_zo_yflip, col_major
+    torch.cuda.set_device(0)
+    K, Wu = args.steps, args.warmup
+    n_nodes, n_meshes, n_mats = 1_000_000, 20_000, 256
+    m = make_draw_model(n_nodes, n_meshes, n_mats, seed=15, invalid_fraction=0.005)
+    n_slots = len(m["slots"])
+    ctx = Context(64, 64, 0)
+    ib = SharedOpaqueIndirect(ctx)
+    ib.buildSharedDrawSlots(m["node_parent"], m["node_local"], m["slots"], m["mesh_infos"], 1 << 21, mesh_bounds=m["mesh_bounds"])
+    proj = perspective_rh_zo_yflip(60.0, 16 / 9, 0.1, 400.0)
+
+    def frame_inputs(i):
+        a = 0.05 * i
+        vp = col_major((proj @ look_at_rh((0, 4, 0), (60 * np.sin(a), 0, 60 * np.cos(a)))).astype(np.float32))   # inside the scene, panning
+        model = np.eye(4, dtype=np.float32)
+        model[0, 3] = 0.01 * i
+        return col_major(model), vp
+
+    inputs = [frame_inputs(i) for i in range(K + Wu)]
+    for i in range(Wu):
+        ib.prepareSharedOpaqueIndirect(*inputs[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(Wu, Wu + K):
+        ib.prepareSharedOpaqueIndirect(*inputs[i])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    draws = []
+    t_dev = []
+    for i in range(Wu, Wu + K):
+        t_dev.append(event_time_ms(lambda: ib.prepareSharedOpaqueIndirect(*inputs[i]), None))
+        draws.append(ib.result()[0])
+    dev_ms = float(np.mean(t_dev))
+    mean_draws = float(np.mean(draws))
+    # algorithmic bytes of one prepare (DESIGN section 12): per node parent 4 + local 64 read, world 64 written;
+    # per slot 16 read + world 64 + bounds 24 read for the test; per surviving draw world 64 + info 12 read,
+    # drawData 64 + command 20 written
+    bytes_per_launch = n_nodes * 132.0 + n_slots * 104.0 + mean_draws * 160.0
+    achieved = bytes_per_launch / (dev_ms * 1e-3) / 1e9
+    out = {
+        "metric": "indirect-build Mslots/s (draw slots processed by prepareSharedOpaqueIndirect / wall time)",
+        "value": n_slots * K / elapsed / 1e6, "unit": "Mslots/s", "n_gpus": 1, "steps": K, "warmup": Wu,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32+u32", "data": "synthetic",
+        "config": {"workload": f"c2: synthetic {n_nodes}-node model, {n_slots} draw slots, {n_meshes} meshes, {n_mats} materials: "
+                               "world matrices + frustum cull + DrawIndexedIndirectCommand compaction",
+                   "mean_draws_after_cull": mean_draws, "parallelism": "single"},
+        "roofline": {"bound": "hbm", "kernel": "vkr_indirect_prepare (k_ib_world + k_ib_count + k_ib_emit + spans)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "launch_ms": dev_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+    }
+    if args.cpu_seconds > 0:
+        from oracle import oracle
+        slots = oracle.sort_draw_slots(m["slots"])
+        reps, t_cpu = 0, 0.0
+        while t_cpu < min(args.cpu_seconds, 10.0) and reps < K:
+            model, vp = inputs[Wu + reps]
+            t1 = time.perf_counter()
+            oracle.prepare_indirect(m["node_parent"], m["node_local"], slots, m["mesh_infos"], model, 1 << 21,
+                                    view_proj=vp, mesh_bounds=m["mesh_bounds"])
+            t_cpu += time.perf_counter() - t1
+            reps += 1
+        out["cpu_baseline"] = {"value": n_slots * reps / t_cpu / 1e6, "unit": "Mslots/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} full frames of the same workload (oracle restatement of FrameManager.cpp:118-175 + frustum test)"}
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
+    if args.workload == "c2":
+        return main_c2(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -50,6 +50,33 @@ def test_prepare_matches_reference_loop(ctx, nodes, meshes, mats, seed):
     run_both(ctx, m, MODEL, 1 << 20)
 
 
+def test_deep_and_interleaved_hierarchies(ctx):
+    """depth > 16 takes the one-launch chain-walk kernel; a DFS-ordered hierarchy (levels interleaved in linear order)
+    exercises the level permutation of the level-per-launch kernel."""
+    deep = make_draw_model(6000, 50, 8, seed=21, max_depth=40)
+    run_both(ctx, deep, MODEL, 1 << 16)
+    m = make_draw_model(5000, 50, 8, seed=22, max_depth=6)
+    # re-number the nodes in DFS pre-order: parents still precede children, levels interleave
+    n = len(m["node_parent"])
+    kids = [[] for _ in range(n)]
+    roots = []
+    for i, p in enumerate(m["node_parent"]):
+        (roots if p < 0 else kids[p]).append(i)
+    dfs, stack = [], roots[::-1]
+    while stack:
+        i = stack.pop()
+        dfs.append(i)
+        stack.extend(kids[i][::-1])
+    new_of = np.empty(n, dtype=np.int64)
+    new_of[dfs] = np.arange(n)
+    par = np.array([-1 if m["node_parent"][i] < 0 else new_of[m["node_parent"][i]] for i in dfs], dtype=np.int32)
+    assert (par < np.arange(n)).all() and (np.diff(par) < 0).any()
+    m2 = dict(m, node_parent=par, node_local=m["node_local"][dfs])
+    m2["slots"] = m["slots"].copy()
+    m2["slots"]["node_linear_index"] = new_of[m["slots"]["node_linear_index"]].astype(np.uint32)
+    run_both(ctx, m2, MODEL, 1 << 16, vp=view_proj())
+
+
 def test_invalid_slots_are_skipped(ctx):
     m = make_draw_model(9000, 100, 16, seed=11, invalid_fraction=0.07)
     ib, n = run_both(ctx, m, I16, 1 << 20)

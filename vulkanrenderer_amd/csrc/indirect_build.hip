@@ -59,6 +59,35 @@ __global__ __launch_bounds__(256) void k_ib_world(const int32_t* parent, const f
     for (int c = 0; c < 4; ++c) world[(size_t)n * 4 + c] = make_float4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
 }
 
+// The same product one hierarchy level per launch (levels known from the upload): parents' matrices are final when a
+// level starts, so each node is one 64 B read of its parent's matrix, one of its local matrix and one 64 B write.
+// Four lanes per node, one result column each: loads and stores are 16 B per lane and contiguous per node.
+__global__ __launch_bounds__(256) void k_ib_world_level(const int32_t* parent, const float4* local, const uint32_t* order,
+                                                        uint32_t first, uint32_t count, Mat16 model, float4* world)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if ((t >> 2) >= count) return;
+    const uint32_t n = order[first + (t >> 2)], j = t & 3u;
+    const int32_t p = parent[n];
+    float4 a0, a1, a2, a3;
+    if (p >= 0) {
+        const float4* pw = world + (size_t)p * 4;
+        a0 = pw[0]; a1 = pw[1]; a2 = pw[2]; a3 = pw[3];
+    } else {
+        a0 = make_float4(model.m[0], model.m[1], model.m[2], model.m[3]);
+        a1 = make_float4(model.m[4], model.m[5], model.m[6], model.m[7]);
+        a2 = make_float4(model.m[8], model.m[9], model.m[10], model.m[11]);
+        a3 = make_float4(model.m[12], model.m[13], model.m[14], model.m[15]);
+    }
+    const float4 b = local[(size_t)n * 4 + j];
+    float4 r;   // column j of A * B, GLM's order: ((A0*b.x + A1*b.y) + A2*b.z) + A3*b.w
+    r.x = ((a0.x * b.x + a1.x * b.y) + a2.x * b.z) + a3.x * b.w;
+    r.y = ((a0.y * b.x + a1.y * b.y) + a2.y * b.z) + a3.y * b.w;
+    r.z = ((a0.z * b.x + a1.z * b.y) + a2.z * b.z) + a3.z * b.w;
+    r.w = ((a0.w * b.x + a1.w * b.y) + a2.w * b.z) + a3.w * b.w;
+    world[(size_t)n * 4 + j] = r;
+}
+
 // BoundingBox::Transform (BoundingBox.h:14-39) + Frustum::Intersects (Frustum.h:18-44)
 VKR_DI bool box_in_frustum(const float4* wm, const float* b, const Planes& pl)
 {
@@ -186,19 +215,26 @@ __global__ __launch_bounds__(256) void k_ib_span_heads(const uint64_t* keys, con
     }
 }
 
-// spans are few (<= 2 x materials): one block orders the head positions and closes the ranges
+// spans are few (one per (doubleSided, material) key): one block ranks the head positions and closes the ranges.
+// Up to IB_SPAN_LDS heads are staged in LDS; beyond that the ranking reads them from global memory.
+constexpr uint32_t IB_SPAN_LDS = 4096;
 __global__ __launch_bounds__(256) void k_ib_span_emit(const uint64_t* keys, const uint32_t* total, uint32_t max_draws,
-                                                      const uint32_t* span_count, uint32_t* head_pos, uint32_t span_capacity,
+                                                      const uint32_t* span_count, const uint32_t* head_pos, uint32_t span_capacity,
                                                       SpanDev* spans)
 {
+    __shared__ uint32_t s_head[IB_SPAN_LDS];
     const uint32_t n = *total < max_draws ? *total : max_draws;
-    uint32_t ns = *span_count < span_capacity ? *span_count : span_capacity;
-    // rank sort of the head positions (distinct values), O(ns^2 / 256) -- ns is at most a few hundred
+    const uint32_t ns = *span_count < span_capacity ? *span_count : span_capacity;
+    const bool staged = ns <= IB_SPAN_LDS;
+    if (staged) {
+        for (uint32_t a = threadIdx.x; a < ns; a += 256u) s_head[a] = head_pos[a];
+        __syncthreads();
+    }
     for (uint32_t a = threadIdx.x; a < ns; a += 256u) {
-        const uint32_t pos = head_pos[a];
+        const uint32_t pos = staged ? s_head[a] : head_pos[a];
         uint32_t rank = 0, next = n;
         for (uint32_t b = 0; b < ns; ++b) {
-            const uint32_t q = head_pos[b];
+            const uint32_t q = staged ? s_head[b] : head_pos[b];
             rank += (q < pos) ? 1u : 0u;
             if (q > pos && q < next) next = q;
         }
@@ -220,7 +256,15 @@ hipError_t indirect_prepare_launch(vkr_ctx* c, const float model[16], const floa
     Planes pl;
     for (int k = 0; k < 24; ++k) pl.p[k] = planes24 ? planes24[k] : 0.0f;
     IB_TRY(hipMemsetAsync(c->d_ib_counters.p, 0, 8, st));      // [0] total survivors, [1] span count
-    if (nn) k_ib_world<<<(nn + 255u) / 256u, 256, 0, st>>>(c->d_ib_parent.p, c->d_ib_local.p, nn, m, c->d_ib_world.p);
+    if (nn && !c->ib_level_first.empty()) {
+        for (size_t l = 0; l + 1 < c->ib_level_first.size(); ++l) {
+            const uint32_t first = c->ib_level_first[l], cnt = c->ib_level_first[l + 1] - first;
+            if (cnt) k_ib_world_level<<<(cnt * 4u + 255u) / 256u, 256, 0, st>>>(c->d_ib_parent.p, c->d_ib_local.p, c->d_ib_order.p,
+                                                                              first, cnt, m, c->d_ib_world.p);
+        }
+    } else if (nn) {
+        k_ib_world<<<(nn + 255u) / 256u, 256, 0, st>>>(c->d_ib_parent.p, c->d_ib_local.p, nn, m, c->d_ib_world.p);
+    }
     if (ns == 0) return hipGetLastError();
     const uint32_t tiles = (ns + IB_TILE - 1) / IB_TILE;
     const int cull = (planes24 && c->d_ib_bounds.p) ? 1 : 0;

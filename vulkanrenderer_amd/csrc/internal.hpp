@@ -107,6 +107,8 @@ struct vkr_ctx {
     vkr::DevBuf<uint64_t> d_ib_keys;
     vkr::DevBuf<uint4> d_ib_spans;
     std::vector<uint4> h_ib_slots;
+    vkr::DevBuf<uint32_t> d_ib_order;             // nodes grouped by hierarchy level (level-per-launch world matrices)
+    std::vector<uint32_t> ib_level_first;         // level l = order[first[l] .. first[l+1]); empty = chain-walk kernel
 
     // ---- BVH
     bool has_bvh = false;

@@ -162,6 +162,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
     c->d_ib_infos.release(); c->d_ib_bounds.release(); c->d_ib_flags.release(); c->d_ib_tile.release();
     c->d_ib_counters.release(); c->d_ib_heads.release(); c->d_ib_keys.release(); c->d_ib_spans.release();
+    c->d_ib_order.release();
     delete c;
 }
 
@@ -493,6 +494,7 @@ int vkr_indirect_upload(vkr_ctx* c, const vkr_indirect_desc* d)
         (d->mesh_count && !d->mesh_infos))
         return fail(c, VKR_ERR_INVALID_ARG, "indirect desc: NULL array with non-zero count");
     if (d->slot_count > (1u << 24)) return fail(c, VKR_ERR_LIMIT, "more than 2^24 draw slots");
+    if (d->node_count > (1u << 28)) return fail(c, VKR_ERR_LIMIT, "more than 2^28 linear nodes");
     if (int rc = set_device(c)) return rc;
     c->has_indirect = false;
     std::vector<int> depth(d->node_count, 0);
@@ -502,6 +504,21 @@ int vkr_indirect_upload(vkr_ctx* c, const vkr_indirect_desc* d)
             return fail(c, VKR_ERR_INVALID_ARG, "linear node %u: parent %d must precede it", i, p);
         depth[i] = p < 0 ? 1 : depth[p] + 1;
         if (depth[i] > VKR_GRAPH_MAX_DEPTH) return fail(c, VKR_ERR_LIMIT, "linear node %u: hierarchy deeper than %d", i, VKR_GRAPH_MAX_DEPTH);
+    }
+    // nodes grouped by level (stable: ascending linear index inside a level) for the level-per-launch world-matrix
+    // kernel; hierarchies deeper than 16 levels keep the one-launch chain-walk kernel
+    int max_depth = 0;
+    for (uint32_t i = 0; i < d->node_count; ++i) max_depth = depth[i] > max_depth ? depth[i] : max_depth;
+    c->ib_level_first.clear();
+    std::vector<uint32_t> order;
+    if (max_depth >= 1 && max_depth <= 16) {
+        std::vector<uint32_t> first(max_depth + 1, 0);
+        for (uint32_t i = 0; i < d->node_count; ++i) ++first[depth[i]];
+        for (int l = 1; l <= max_depth; ++l) first[l] += first[l - 1];      // first[l] = end of level l (1-based)
+        order.resize(d->node_count);
+        std::vector<uint32_t> cursor(first.begin(), first.end() - 1);        // start of level l+1 = end of level l
+        for (uint32_t i = 0; i < d->node_count; ++i) order[cursor[depth[i] - 1]++] = i;
+        c->ib_level_first = first;
     }
     // the sort of buildSharedDrawSlots (FrameManager.cpp:110-115), once per model like the reference
     c->h_ib_slots.resize(d->slot_count);
@@ -532,6 +549,8 @@ int vkr_indirect_upload(vkr_ctx* c, const vkr_indirect_desc* d)
     HIP_OR_FAIL(c, c->d_ib_spans.alloc(c->ib_span_capacity));
     HIP_OR_FAIL(c, c->d_ib_keys.alloc(d->slot_count ? d->slot_count : 1));
     HIP_OR_FAIL(c, hipMemset(c->d_ib_counters.p, 0, 8));
+    HIP_OR_FAIL(c, c->d_ib_order.alloc(order.empty() ? 1 : order.size()));
+    if (!order.empty()) HIP_OR_FAIL(c, hipMemcpy(c->d_ib_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice));
     if (d->node_count) {
         HIP_OR_FAIL(c, hipMemcpy(c->d_ib_parent.p, d->node_parent, (size_t)d->node_count * 4, hipMemcpyHostToDevice));
         HIP_OR_FAIL(c, hipMemcpy(c->d_ib_local.p, d->node_local, (size_t)d->node_count * 64, hipMemcpyHostToDevice));
