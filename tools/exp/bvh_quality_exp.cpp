@@ -1,0 +1,181 @@
+// Offline experiment (CPU, not shipped): how much traversal work would a better binary tree save?
+// Builds over the same triangle soup: (1) LBVH (Morton, Karras-equivalent split on the highest differing bit),
+// (2) binned-SAH top-down, (3) PLOC (radius r); collapses each to 4-ary (largest-area opening, leaves <= 4 tris)
+// and counts node visits / triangle tests for short AO-like rays (closest hit, LIFO, cull by tbest).
+// input: binary file  [u32 n][n * 9 floats]   usage: exp tris.bin
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+struct V3 { float x, y, z; };
+static V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+struct Box { V3 lo{1e30f, 1e30f, 1e30f}, hi{-1e30f, -1e30f, -1e30f};
+    void grow(V3 p) { lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)}; hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)}; }
+    void grow(const Box& b) { grow(b.lo); grow(b.hi); }
+    float area() const { V3 d = hi - lo; return 2.f * (d.x * d.y + d.y * d.z + d.z * d.x); } };
+struct Tri { V3 a, b, c; };
+struct BNode { Box box; int l = -1, r = -1; int first = 0, count = 0; };   // leaf if l < 0 (count == 1 for leaves at build)
+static std::vector<Tri> T; static std::vector<Box> TB; static std::vector<V3> TC;
+
+static uint64_t expand21(uint64_t v) { v &= 0x1fffff; v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull; v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull; return v; }
+
+// a binary tree = nodes + order (triangle ids in leaf order)
+struct Tree { std::vector<BNode> n; std::vector<int> order; int root = 0; };
+
+static int lbvh_rec(Tree& t, const std::vector<uint64_t>& key, int lo, int hi)   // [lo, hi]
+{
+    int id = (int)t.n.size(); t.n.emplace_back();
+    if (lo == hi) { t.n[id].first = lo; t.n[id].count = 1; t.n[id].box = TB[t.order[lo]]; return id; }
+    int split;
+    if (key[lo] == key[hi]) split = (lo + hi) >> 1;
+    else { int pre = __builtin_clzll(key[lo] ^ key[hi]); int s = lo, step = hi - lo;
+        do { step = (step + 1) >> 1; int ns = s + step; if (ns < hi && __builtin_clzll(key[lo] ^ key[ns]) > pre) s = ns; } while (step > 1);
+        split = s; }
+    int l = lbvh_rec(t, key, lo, split), r = lbvh_rec(t, key, split + 1, hi);
+    t.n[id].l = l; t.n[id].r = r; t.n[id].first = lo; t.n[id].count = hi - lo + 1;
+    t.n[id].box = t.n[l].box; t.n[id].box.grow(t.n[r].box); return id;
+}
+static std::vector<uint64_t> morton_sorted(std::vector<int>& order)
+{
+    Box cb; for (auto& c : TC) cb.grow(c);
+    int n = (int)T.size(); std::vector<std::pair<uint64_t, int>> kv(n);
+    V3 ext = cb.hi - cb.lo;
+    for (int i = 0; i < n; ++i) {
+        uint64_t x = (uint64_t)std::min(2097151.0, (TC[i].x - cb.lo.x) / std::max(ext.x, 1e-20f) * 2097152.0);
+        uint64_t y = (uint64_t)std::min(2097151.0, (TC[i].y - cb.lo.y) / std::max(ext.y, 1e-20f) * 2097152.0);
+        uint64_t z = (uint64_t)std::min(2097151.0, (TC[i].z - cb.lo.z) / std::max(ext.z, 1e-20f) * 2097152.0);
+        kv[i] = {expand21(x) << 2 | expand21(y) << 1 | expand21(z), i}; }
+    std::sort(kv.begin(), kv.end());
+    order.resize(n); std::vector<uint64_t> key(n);
+    for (int i = 0; i < n; ++i) { key[i] = kv[i].first; order[i] = kv[i].second; }
+    return key;
+}
+static Tree build_lbvh() { Tree t; auto key = morton_sorted(t.order); t.n.reserve(2 * T.size()); t.root = lbvh_rec(t, key, 0, (int)T.size() - 1); return t; }
+
+static int sah_rec(Tree& t, int lo, int hi)   // [lo, hi)
+{
+    int id = (int)t.n.size(); t.n.emplace_back();
+    Box b, cb; for (int i = lo; i < hi; ++i) { b.grow(TB[t.order[i]]); cb.grow(TC[t.order[i]]); }
+    t.n[id].box = b; t.n[id].first = lo; t.n[id].count = hi - lo;
+    if (hi - lo == 1) return id;
+    const int NB = 16; float best = 1e30f; int bax = -1, bsp = 0;
+    for (int ax = 0; ax < 3; ++ax) {
+        float c0 = (&cb.lo.x)[ax], c1 = (&cb.hi.x)[ax]; if (c1 - c0 < 1e-9f) continue;
+        Box bb[NB]; int bc[NB] = {0};
+        for (int i = lo; i < hi; ++i) { int k = std::min(NB - 1, (int)(((&TC[t.order[i]].x)[ax] - c0) / (c1 - c0) * NB)); bb[k].grow(TB[t.order[i]]); bc[k]++; }
+        float ra[NB]; Box acc; int cnt = 0; int rc[NB];
+        for (int k = NB - 1; k > 0; --k) { if (bc[k]) acc.grow(bb[k]); cnt += bc[k]; ra[k] = cnt ? acc.area() : 0.f; rc[k] = cnt; }
+        Box la; int lc = 0;
+        for (int k = 0; k < NB - 1; ++k) { if (bc[k]) la.grow(bb[k]); lc += bc[k]; if (lc == 0 || rc[k + 1] == 0) continue; float c = la.area() * lc + ra[k + 1] * rc[k + 1]; if (c < best) { best = c; bax = ax; bsp = k; } }
+    }
+    int mid;
+    if (bax < 0) mid = (lo + hi) >> 1;
+    else { float c0 = (&cb.lo.x)[bax], c1 = (&cb.hi.x)[bax];
+        mid = (int)(std::partition(t.order.begin() + lo, t.order.begin() + hi, [&](int i) { return std::min(NB - 1, (int)(((&TC[i].x)[bax] - c0) / (c1 - c0) * NB)) <= bsp; }) - t.order.begin());
+        if (mid == lo || mid == hi) mid = (lo + hi) >> 1; }
+    int l = sah_rec(t, lo, mid), r = sah_rec(t, mid, hi); t.n[id].l = l; t.n[id].r = r; return id;
+}
+static Tree build_sah() { Tree t; t.order.resize(T.size()); for (size_t i = 0; i < T.size(); ++i) t.order[i] = (int)i; t.n.reserve(2 * T.size()); t.root = sah_rec(t, 0, (int)T.size()); return t; }
+
+// PLOC over Morton-sorted leaves; leaf order is rebuilt by DFS afterwards
+static void dfs_order(Tree& t, int id, std::vector<int>& out, const std::vector<int>& leaf_tri)
+{
+    std::vector<int> st{id};
+    // iterative post-fix of first/count
+    std::vector<std::pair<int, int>> stack{{id, 0}};
+    while (!stack.empty()) { auto [n, ph] = stack.back(); stack.pop_back();
+        if (t.n[n].l < 0) { t.n[n].first = (int)out.size(); t.n[n].count = 1; out.push_back(leaf_tri[n]); continue; }
+        if (ph == 0) { stack.push_back({n, 1}); stack.push_back({t.n[n].r, 0}); stack.push_back({t.n[n].l, 0}); }
+        else { t.n[n].first = t.n[t.n[n].l].first; t.n[n].count = t.n[t.n[n].l].count + t.n[t.n[n].r].count; } }
+}
+static Tree build_ploc(int radius)
+{
+    Tree t; std::vector<int> order; morton_sorted(order);
+    int n = (int)T.size(); t.n.reserve(2 * n); std::vector<int> leaf_tri(2 * n, -1);
+    std::vector<int> cl(n);
+    for (int i = 0; i < n; ++i) { t.n.emplace_back(); t.n[i].box = TB[order[i]]; leaf_tri[i] = order[i]; cl[i] = i; }
+    int iters = 0;
+    while (cl.size() > 1) { ++iters; int m = (int)cl.size(); std::vector<int> nn(m);
+        for (int i = 0; i < m; ++i) { float best = 1e30f; int bj = -1;
+            for (int j = std::max(0, i - radius); j <= std::min(m - 1, i + radius); ++j) { if (j == i) continue; Box b = t.n[cl[i]].box; b.grow(t.n[cl[j]].box); float a = b.area(); if (a < best) { best = a; bj = j; } }
+            nn[i] = bj; }
+        std::vector<int> next; next.reserve(m);
+        for (int i = 0; i < m; ++i) { int j = nn[i];
+            if (nn[j] == i) { if (i < j) { int id = (int)t.n.size(); t.n.emplace_back(); t.n[id].l = cl[i]; t.n[id].r = cl[j]; t.n[id].box = t.n[cl[i]].box; t.n[id].box.grow(t.n[cl[j]].box); next.push_back(id); } }
+            else next.push_back(cl[i]); }
+        cl.swap(next); }
+    t.root = cl[0]; dfs_order(t, t.root, t.order, leaf_tri);
+    fprintf(stderr, "ploc r=%d iterations %d\n", radius, iters);
+    return t;
+}
+
+// 4-ary collapse: open largest-area child with > 4 tris, up to twice
+struct WNode { Box cb[4]; int ref[4]; int nch; };   // ref >= 0 wide node, < 0 leaf ~(binary node)
+struct Wide { std::vector<WNode> w; const Tree* t; };
+static Wide collapse(const Tree& t)
+{
+    Wide W; W.t = &t; std::vector<int> bin{t.root}; W.w.emplace_back();
+    for (size_t wi = 0; wi < bin.size(); ++wi) {
+        int b = bin[wi]; std::vector<int> ch;
+        if (t.n[b].count <= 4 || t.n[b].l < 0) ch = {b};
+        else { ch = {t.n[b].l, t.n[b].r};
+            for (int k = 0; k < 2; ++k) { int bi = -1; float ba = -1;
+                for (size_t c = 0; c < ch.size(); ++c) if (t.n[ch[c]].count > 4 && t.n[ch[c]].l >= 0 && t.n[ch[c]].box.area() > ba) { ba = t.n[ch[c]].box.area(); bi = (int)c; }
+                if (bi < 0) break; int o = ch[bi]; ch[bi] = t.n[o].l; ch.push_back(t.n[o].r); } }
+        WNode wn; wn.nch = (int)ch.size();
+        for (int c = 0; c < wn.nch; ++c) { wn.cb[c] = t.n[ch[c]].box;
+            if (t.n[ch[c]].count <= 4 || t.n[ch[c]].l < 0) wn.ref[c] = ~ch[c];
+            else { wn.ref[c] = (int)bin.size(); bin.push_back(ch[c]); W.w.emplace_back(); } }
+        W.w[wi] = wn; }
+    return W;
+}
+static bool slab(const Box& b, V3 o, V3 inv, float tmin, float tmax)
+{
+    float t0 = (b.lo.x - o.x) * inv.x, t1 = (b.hi.x - o.x) * inv.x; if (t0 > t1) std::swap(t0, t1); tmin = std::max(tmin, t0); tmax = std::min(tmax, t1);
+    t0 = (b.lo.y - o.y) * inv.y; t1 = (b.hi.y - o.y) * inv.y; if (t0 > t1) std::swap(t0, t1); tmin = std::max(tmin, t0); tmax = std::min(tmax, t1);
+    t0 = (b.lo.z - o.z) * inv.z; t1 = (b.hi.z - o.z) * inv.z; if (t0 > t1) std::swap(t0, t1); tmin = std::max(tmin, t0); tmax = std::min(tmax, t1);
+    return tmin <= tmax;
+}
+static bool tri_hit(const Tri& tr, V3 o, V3 d, float tmin, float& tbest)
+{
+    V3 e1 = tr.b - tr.a, e2 = tr.c - tr.a, p = cross(d, e2); float det = dot(e1, p); if (std::fabs(det) < 1e-12f) return false;
+    float id = 1.f / det; V3 tv = o - tr.a; float u = dot(tv, p) * id; if (u < 0 || u > 1) return false;
+    V3 q = cross(tv, e1); float v = dot(d, q) * id; if (v < 0 || u + v > 1) return false; float tt = dot(e2, q) * id;
+    if (tt > tmin && tt < tbest) { tbest = tt; return true; } return false;
+}
+static void trace(const Wide& W, V3 o, V3 d, float tmax, uint64_t& nodes, uint64_t& tris)
+{
+    V3 inv{1.f / d.x, 1.f / d.y, 1.f / d.z}; float tbest = tmax; std::vector<int> st{0};
+    while (!st.empty()) { int r = st.back(); st.pop_back();
+        if (r >= 0) { ++nodes; const WNode& w = W.w[r]; for (int c = 0; c < w.nch; ++c) if (slab(w.cb[c], o, inv, 1e-3f, tbest)) st.push_back(w.ref[c]); }
+        else { const BNode& b = W.t->n[~r]; for (int k = 0; k < b.count; ++k) { ++tris; tri_hit(T[W.t->order[b.first + k]], o, d, 1e-3f, tbest); } } }
+}
+static double sah_cost(const Tree& t) { double c = 0; float ra = t.n[t.root].box.area(); for (auto& n : t.n) c += (n.l < 0 ? 1.0 : 1.2) * n.box.area() / ra; return c; }
+
+int main(int argc, char** argv)
+{
+    FILE* f = fopen(argv[1], "rb"); uint32_t n; if (fread(&n, 4, 1, f) != 1) return 1; T.resize(n); if (fread(T.data(), 36, n, f) != n) return 1; fclose(f);
+    TB.resize(n); TC.resize(n);
+    for (uint32_t i = 0; i < n; ++i) { TB[i].grow(T[i].a); TB[i].grow(T[i].b); TB[i].grow(T[i].c); TC[i] = (TB[i].lo + TB[i].hi) * 0.5f; }
+    // rays: origin on a random triangle, cosine-ish hemisphere about its normal, both sides
+    std::mt19937 rng(7); std::uniform_real_distribution<float> U(0, 1); int NR = 200000; std::vector<V3> ro(NR), rd(NR);
+    for (int i = 0; i < NR; ++i) { const Tri& tr = T[rng() % n]; float u = U(rng), v = U(rng); if (u + v > 1) { u = 1 - u; v = 1 - v; }
+        V3 p = tr.a + (tr.b - tr.a) * u + (tr.c - tr.a) * v; V3 nn = cross(tr.b - tr.a, tr.c - tr.a); float l = std::sqrt(dot(nn, nn)); if (l < 1e-12f) { --i; continue; } nn = nn * (1.f / l);
+        if (nn.y < 0) nn = nn * -1.f; V3 dd; do { dd = {U(rng) * 2 - 1, U(rng) * 2 - 1, U(rng) * 2 - 1}; } while (dot(dd, dd) > 1 || dot(dd, dd) < 1e-4f); dd = dd * (1.f / std::sqrt(dot(dd, dd))); if (dot(dd, nn) < 0) dd = dd * -1.f;
+        ro[i] = p + nn * 1e-3f; rd[i] = dd; }
+    float radius = argc > 2 ? atof(argv[2]) : 1.2f;
+    auto eval = [&](const char* name, const Tree& t) { Wide W = collapse(t); uint64_t nv = 0, tt = 0; for (int i = 0; i < NR; ++i) trace(W, ro[i], rd[i], radius, nv, tt);
+        printf("%-10s binary SAH %.1f  wide nodes %zu  nodes/ray %.2f  tris/ray %.2f\n", name, sah_cost(t), W.w.size(), (double)nv / NR, (double)tt / NR); fflush(stdout); };
+    { Tree t = build_lbvh(); eval("lbvh", t); }
+    { Tree t = build_ploc(8); eval("ploc r8", t); }
+    { Tree t = build_ploc(25); eval("ploc r25", t); }
+    { Tree t = build_sah(); eval("sah16", t); }
+    return 0;
+}
