@@ -318,6 +318,37 @@ VKR_API int vkr_indirect_prepare(vkr_ctx* ctx, const float model_matrix[16], con
 VKR_API int vkr_indirect_result(vkr_ctx* ctx, uint32_t* draw_count, vkr_bucket_span* spans, uint32_t span_capacity,
                                 uint32_t* span_count, void* stream);
 
+/* ---------------------------------------------------------------- IBL precompute --------- */
+
+/* SURVEY 8(f) row 3 (BASELINE configs[1]).  All images are tightly packed DEVICE arrays:
+ *   equirect   RGBA32F [height][width][4]           (HdrTextureLoader: stbi_loadf RGBA, HdrTextureLoader.cpp:20-28)
+ *   env cube   RGBA32F [6][S][S][4]                 (EquirectToCubemap.cpp:75), faces +X -X +Y -Y +Z -Z, Vulkan layout
+ *   irradiance RGBA16F [6][S][S][4]                 (IblPrecompute.cpp:115-120)
+ *   prefilter  RGBA16F, mip-major: mip m = [6][S>>m][S>>m][4], m < floor(log2 S) + 1   (IblPrecompute.cpp:285,376-387)
+ *   BRDF LUT   RG16F   [S][S][2], column = NdotV, row = roughness                        (IblPrecompute.cpp:472-546)
+ * Cube sizes must be powers of two. */
+
+/* Replaces: EquirectToCubemap::convert (EquirectToCubemap.cpp:66-398, equirect_to_cubemap.frag); the equirect
+ * sampler is LINEAR, U repeat, V clamp-to-edge (Renderer.cpp:113-115).  Reference cube_size: 512 (Renderer.cpp:117). */
+VKR_API int vkr_ibl_equirect_to_cube(vkr_ctx* ctx, const float* equirect, uint32_t width, uint32_t height,
+                                     float* env_cube, uint32_t cube_size, void* stream);
+/* Replaces: IblPrecompute::compute step 1 (IblPrecompute.cpp:107-283, irradiance_convolution.frag). Reference size: 32. */
+VKR_API int vkr_ibl_irradiance(vkr_ctx* ctx, const float* env_cube, uint32_t env_size, uint16_t* irradiance,
+                               uint32_t size, void* stream);
+/* Replaces: step 2 (IblPrecompute.cpp:285-470, prefilter.frag), every mip, roughness = mip / (mips - 1) (:383).
+ * Reference size: 128 (8 mips); `prefilter` holds vkr_ibl_prefilter_texels(size) * 4 halves. */
+VKR_API int vkr_ibl_prefilter(vkr_ctx* ctx, const float* env_cube, uint32_t env_size, uint16_t* prefilter,
+                              uint32_t size, void* stream);
+/* Replaces: step 3 (IblPrecompute.cpp:472-546, brdf_integrate.frag).  Reference size: 512. */
+VKR_API int vkr_ibl_brdf_lut(vkr_ctx* ctx, uint16_t* brdf_lut, uint32_t size, void* stream);
+/* Replaces: IblPrecompute::compute (IblPrecompute.cpp:75-561): the three steps above on one stream. */
+VKR_API int vkr_ibl_compute(vkr_ctx* ctx, const float* env_cube, uint32_t env_size, uint16_t* irradiance,
+                            uint32_t irradiance_size, uint16_t* prefilter, uint32_t prefilter_size,
+                            uint16_t* brdf_lut, uint32_t brdf_lut_size, void* stream);
+/* mipCount() of IblPrecompute.cpp:68-71 and the number of texels (all faces, all mips) of a prefilter map. */
+VKR_API uint32_t vkr_ibl_prefilter_mip_count(uint32_t size);
+VKR_API size_t vkr_ibl_prefilter_texels(uint32_t size);
+
 /* ---------------------------------------------------------------- counters -------------- */
 
 typedef struct vkr_trace_stats {

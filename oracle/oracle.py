@@ -33,8 +33,8 @@ class _Scene(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "rtao_oracle.cpp")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "rtao_oracle.cpp"), os.path.join(_HERE, "ibl_oracle.cpp")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
@@ -295,6 +295,107 @@ def prepare_indirect(node_parent, node_local, sorted_slots, mesh_infos, model, m
                                _p(m), int(max_draws), _p(vp) if vp is not None else None,
                                _p(mb) if mb is not None else None, _p(dd), cm.ctypes.data, sp.ctypes.data, cap, C.byref(ns))
     return int(n), dd[:n], cm[:n], sp[:ns.value]
+
+
+# ---------------------------------------------------------------- IBL precompute (oracle/ibl_oracle.cpp)
+def prefilter_mip_count(size: int) -> int:
+    return int(np.floor(np.log2(size))) + 1            # IblPrecompute.cpp:68-71
+
+
+def prefilter_mip_offsets(size: int):
+    """Offsets (in halves) of each mip in the mip-major packed RGBA16F prefilter buffer, plus the total."""
+    offs, o = [], 0
+    for m in range(prefilter_mip_count(size)):
+        offs.append(o)
+        sm = max(1, size >> m)
+        o += 6 * sm * sm * 4
+    return offs, o
+
+
+def ibl_equirect_to_cube(equirect, cube_size):
+    L = lib()
+    eq = _f32(equirect)
+    h, w = eq.shape[0], eq.shape[1]
+    out = np.zeros((6, cube_size, cube_size, 4), dtype=np.float32)
+    L.orc_ibl_equirect_to_cube.restype = None
+    L.orc_ibl_equirect_to_cube.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.orc_ibl_equirect_to_cube(_p(eq), w, h, _p(out), cube_size)
+    return out
+
+
+def ibl_irradiance(cube, size, order=0):
+    L = lib()
+    c = _f32(cube)
+    out = np.zeros((6, size, size, 4), dtype=np.uint16)
+    L.orc_ibl_irradiance.restype = None
+    L.orc_ibl_irradiance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.orc_ibl_irradiance(_p(c), c.shape[1], _p(out), size, order)
+    return out
+
+
+def ibl_prefilter(cube, size, order=0):
+    L = lib()
+    c = _f32(cube)
+    _, total = prefilter_mip_offsets(size)
+    out = np.zeros(total, dtype=np.uint16)
+    L.orc_ibl_prefilter.restype = None
+    L.orc_ibl_prefilter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.orc_ibl_prefilter(_p(c), c.shape[1], _p(out), size, order)
+    return out
+
+
+def ibl_brdf_lut(size):
+    L = lib()
+    out = np.zeros((size, size, 2), dtype=np.uint16)
+    L.orc_ibl_brdf_lut.restype = None
+    L.orc_ibl_brdf_lut.argtypes = [C.c_void_p, C.c_int]
+    L.orc_ibl_brdf_lut(_p(out), size)
+    return out
+
+
+def ibl_sample_cube(cube, direction):
+    L = lib()
+    c = _f32(cube)
+    d = _f32(direction)
+    out = np.zeros(3, dtype=np.float32)
+    L.orc_ibl_sample_cube.restype = None
+    L.orc_ibl_sample_cube.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_ibl_sample_cube(_p(c), c.shape[1], _p(d), _p(out))
+    return out
+
+
+def ibl_sample_equirect(equirect, direction):
+    L = lib()
+    eq = _f32(equirect)
+    d = _f32(direction)
+    out = np.zeros(3, dtype=np.float32)
+    L.orc_ibl_sample_equirect.restype = None
+    L.orc_ibl_sample_equirect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_ibl_sample_equirect(_p(eq), eq.shape[1], eq.shape[0], _p(d), _p(out))
+    return out
+
+
+def ibl_texel_dir(face, x, y, size):
+    L = lib()
+    out = np.zeros(3, dtype=np.float32)
+    L.orc_ibl_texel_dir.restype = None
+    L.orc_ibl_texel_dir.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_ibl_texel_dir(face, x, y, size, _p(out))
+    return out
+
+
+def det_atan2(y, x):
+    L = lib()
+    L.orc_atan2.restype = C.c_float
+    L.orc_atan2.argtypes = [C.c_float, C.c_float]
+    return float(L.orc_atan2(float(y), float(x)))
+
+
+def det_asin(x):
+    L = lib()
+    L.orc_asin.restype = C.c_float
+    L.orc_asin.argtypes = [C.c_float]
+    return float(L.orc_asin(float(x)))
 
 
 def atrous(ubo, step, src, depth, normal, y0=0, y1=None):

@@ -1,0 +1,111 @@
+"""GPU parity of the IBL precompute (BASELINE configs[1]) through the C ABI against
+oracle/ibl_oracle.cpp.  Bar: bit-exact for every map -- the env cube, the BRDF LUT (running sums, the shader's own
+order) and, for irradiance / prefilter, the oracle evaluated in the product's documented two-level summation order
+(order = 1); against the shaders' single running sum (order = 0) the bar is <= 1 fp16 ulp per component with
+>= 97 % of components identical (the tolerance tests/test_ibl_oracle.py pins between the two orders)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from vulkanrenderer_amd.scenes import make_sky_hdr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vulkanrenderer_amd import Context
+    c = Context(32, 32)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def sky():
+    return make_sky_hdr(512, 256)
+
+
+def to_np16(t):
+    return t.cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("W,H,S", [(512, 256, 64), (64, 32, 128), (100, 37, 16), (1, 1, 4)])
+def test_equirect_to_cube_bit_exact(ctx, W, H, S):
+    from vulkanrenderer_amd import EquirectToCubemap
+    eq = make_sky_hdr(W, H, seed=W + H)
+    got = EquirectToCubemap.convert(ctx, torch.from_numpy(eq).to(ctx.device), S).cpu().numpy()
+    want = oracle.ibl_equirect_to_cube(eq, S)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_ibl_compute_bit_exact_small(ctx, sky):
+    from vulkanrenderer_amd import EquirectToCubemap, IblPrecompute
+    cube_np = oracle.ibl_equirect_to_cube(sky, 64)
+    cube = EquirectToCubemap.convert(ctx, torch.from_numpy(sky).to(ctx.device), 64)
+    assert cube.cpu().numpy().tobytes() == cube_np.tobytes()
+    res = IblPrecompute.compute(ctx, cube, irradiance_size=8, prefilter_size=16, brdf_lut_size=64)
+    irr, pre, lut = to_np16(res.irradiance), to_np16(res.prefilter), to_np16(res.brdf_lut)
+    assert lut.tobytes() == oracle.ibl_brdf_lut(64).tobytes()
+    assert irr.tobytes() == oracle.ibl_irradiance(cube_np, 8, 1).tobytes()
+    assert pre.tobytes() == oracle.ibl_prefilter(cube_np, 16, 1).tobytes()
+    # against the shaders' own running sums
+    for got, want in ((irr, oracle.ibl_irradiance(cube_np, 8, 0)), (pre, oracle.ibl_prefilter(cube_np, 16, 0))):
+        d = np.abs(got.reshape(-1).astype(np.int32) - want.reshape(-1).astype(np.int32))
+        assert d.max() <= 1 and (d == 0).mean() > 0.97
+    # the mip view helper agrees with the packed layout
+    offs, total = oracle.prefilter_mip_offsets(16)
+    assert res.prefilter.numel() == total
+    assert to_np16(res.prefilter_mip(2)).tobytes() == pre[offs[2]:offs[3]].tobytes()
+    # roughness 0 (mip 0) is the environment itself, sampled at the texel centre
+    m0 = to_np16(res.prefilter_mip(0)).view(np.float16).astype(np.float32)
+    d = oracle.ibl_texel_dir(4, 5, 9, 16)
+    assert np.allclose(m0[4, 9, 5, :3], oracle.ibl_sample_cube(cube_np, d), rtol=2e-3)
+
+
+def test_constant_environment_on_gpu(ctx):
+    from vulkanrenderer_amd import IblPrecompute
+    cube = torch.ones((6, 8, 8, 4), dtype=torch.float32, device=ctx.device)
+    cube[..., 0] = 3.0
+    res = IblPrecompute.compute(ctx, cube, irradiance_size=4, prefilter_size=4, brdf_lut_size=8)
+    pre = to_np16(res.prefilter).view(np.float16).astype(np.float32).reshape(-1, 4)
+    assert np.allclose(pre, (3.0, 1.0, 1.0, 1.0), rtol=1e-3)
+    th = np.arange(63) * 0.025
+    k = np.pi * np.mean(np.cos(th) * np.sin(th))
+    irr = to_np16(res.irradiance).view(np.float16).astype(np.float32)
+    assert np.allclose(irr[..., 0], 3.0 * k, rtol=2e-3) and np.allclose(irr[..., 1], k, rtol=2e-3)
+
+
+def test_errors(ctx):
+    from vulkanrenderer_amd import EquirectToCubemap, IblPrecompute
+    with pytest.raises(ValueError):
+        EquirectToCubemap.convert(ctx, torch.zeros((4, 4, 3), device=ctx.device), 8)
+    with pytest.raises(RuntimeError, match="power of two"):
+        EquirectToCubemap.convert(ctx, torch.zeros((4, 4, 4), device=ctx.device), 24)
+    with pytest.raises(RuntimeError, match="powers of two"):
+        IblPrecompute.compute(ctx, torch.zeros((6, 8, 8, 4), device=ctx.device), irradiance_size=12)
+
+
+def test_reference_sizes_full(ctx, sky):
+    """BASELINE configs[1] at the reference's sizes (512^2 env, 32^2 irradiance, 128^2 prefilter x 8 mips, 512^2 LUT):
+    every map bit-exact in full (the oracle needs a few seconds on 8 threads), plus size-independent properties of the
+    prefilter (alpha 1, finite, mip 0 == the environment sampled at the texel centres)."""
+    from vulkanrenderer_amd import EquirectToCubemap, IblPrecompute
+    cube = EquirectToCubemap.convert(ctx, torch.from_numpy(sky).to(ctx.device), 512)
+    cube_np = cube.cpu().numpy()
+    assert cube_np.tobytes() == oracle.ibl_equirect_to_cube(sky, 512).tobytes()
+    res = IblPrecompute.compute(ctx, cube)
+    assert to_np16(res.brdf_lut).tobytes() == oracle.ibl_brdf_lut(512).tobytes()
+    assert to_np16(res.irradiance).tobytes() == oracle.ibl_irradiance(cube_np, 32, 1).tobytes()
+    pre = to_np16(res.prefilter)
+    offs, total = oracle.prefilter_mip_offsets(128)
+    assert total == pre.size and len(offs) == 8
+    assert pre.tobytes() == oracle.ibl_prefilter(cube_np, 128, 1).tobytes()
+    f = pre.view(np.float16).astype(np.float32).reshape(-1, 4)
+    assert np.isfinite(f).all() and (f[:, 3] == 1.0).all()
+    m0 = to_np16(res.prefilter_mip(0)).view(np.float16).astype(np.float32)
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        fc, x, y = int(rng.integers(6)), int(rng.integers(128)), int(rng.integers(128))
+        want = oracle.ibl_sample_cube(cube_np, oracle.ibl_texel_dir(fc, x, y, 128))
+        assert np.allclose(m0[fc, y, x, :3], want, rtol=2e-3, atol=1e-3)

@@ -116,6 +116,13 @@ SYMBOLS = {
     "vkr_indirect_slots_download": (C.c_int, [_P, _P]),
     "vkr_indirect_prepare": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, _P, C.c_uint32, _P]),
     "vkr_indirect_result": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_uint32, C.POINTER(C.c_uint32), _P]),
+    "vkr_ibl_equirect_to_cube": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P]),
+    "vkr_ibl_irradiance": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    "vkr_ibl_prefilter": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    "vkr_ibl_brdf_lut": (C.c_int, [_P, _P, C.c_uint32, _P]),
+    "vkr_ibl_compute": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    "vkr_ibl_prefilter_mip_count": (C.c_uint32, [C.c_uint32]),
+    "vkr_ibl_prefilter_texels": (C.c_size_t, [C.c_uint32]),
     "vkr_trace_stats_enable": (C.c_int, [_P, C.c_int]),
     "vkr_trace_stats_get": (C.c_int, [_P, C.POINTER(TraceStats), C.c_int]),
 }

@@ -40,7 +40,14 @@ VKR_DI V3 normalize3(V3 a) { return a * inversesqrt(dot3(a, a)); }
 VKR_DI float length3(V3 a) { return sqrt_(dot3(a, a)); }
 
 VKR_DI float half_to_float(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-VKR_DI uint16_t float_to_half(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// fp32 -> fp16, round to nearest even.  The empty asm pins the fp32 value: without it the compiler may fold a preceding
+// fp32 multiply into v_fma_mixlo_f16, which rounds the exact product once -- a different result from "round to fp32,
+// then to fp16" on ties (seen in k_ibl_irradiance: 1 texel component in ~10^4).
+VKR_DI uint16_t float_to_half(float f)
+{
+    asm volatile("" : "+v"(f));
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
 
 VKR_DI uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 VKR_DI float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }

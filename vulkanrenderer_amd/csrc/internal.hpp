@@ -110,6 +110,9 @@ struct vkr_ctx {
     vkr::DevBuf<uint32_t> d_ib_order;             // nodes grouped by hierarchy level (level-per-launch world matrices)
     std::vector<uint32_t> ib_level_first;         // level l = order[first[l] .. first[l+1]); empty = chain-walk kernel
 
+    // ---- IBL precompute scratch: irradiance sin/cos tables (512 float2) + GGX half-vector table (1024 float4)
+    vkr::DevBuf<float> d_ibl_tables;
+
     // ---- BVH
     bool has_bvh = false;
     uint32_t morton_bits = 21;

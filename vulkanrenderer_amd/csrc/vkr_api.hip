@@ -162,7 +162,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
     c->d_ib_infos.release(); c->d_ib_bounds.release(); c->d_ib_flags.release(); c->d_ib_tile.release();
     c->d_ib_counters.release(); c->d_ib_heads.release(); c->d_ib_keys.release(); c->d_ib_spans.release();
-    c->d_ib_order.release();
+    c->d_ib_order.release(); c->d_ibl_tables.release();
     delete c;
 }
 

@@ -262,6 +262,58 @@ class SharedOpaqueIndirect:
         return n, dd, cm, spans
 
 
+class IblResult:
+    """IblResult of IblPrecompute.h:7-22 as device tensors (views into packed buffers)."""
+
+    def __init__(self, irradiance, prefilter, prefilter_size, brdf_lut):
+        self.irradiance = irradiance            # int16 view of RGBA16F [6, S, S, 4]
+        self.prefilter = prefilter              # int16 view of RGBA16F, mip-major packed
+        self.prefilter_size = prefilter_size
+        self.brdf_lut = brdf_lut                # int16 view of RG16F [S, S, 2]
+
+    def prefilter_mip(self, mip: int) -> torch.Tensor:
+        off = 0
+        for m in range(mip):
+            sm = max(1, self.prefilter_size >> m)
+            off += 6 * sm * sm * 4
+        sm = max(1, self.prefilter_size >> mip)
+        return self.prefilter[off:off + 6 * sm * sm * 4].view(6, sm, sm, 4)
+
+
+class EquirectToCubemap:
+    """EquirectToCubemap::convert (EquirectToCubemap.cpp:66-398)."""
+
+    @staticmethod
+    def convert(ctx: Context, equirect: torch.Tensor, cube_size: int = 512) -> torch.Tensor:
+        if equirect.dtype != torch.float32 or equirect.dim() != 3 or equirect.shape[2] != 4 or not equirect.is_cuda:
+            raise ValueError("equirect must be a CUDA float32 [H, W, 4] tensor (RGBA32F)")
+        eq = equirect.contiguous()
+        cube = torch.empty((6, cube_size, cube_size, 4), dtype=torch.float32, device=ctx.device)
+        _check(ctx.handle, ctx.lib.vkr_ibl_equirect_to_cube(ctx.handle, eq.data_ptr(), eq.shape[1], eq.shape[0],
+                                                            cube.data_ptr(), cube_size, ctx.stream()), "vkr_ibl_equirect_to_cube")
+        return cube
+
+
+class IblPrecompute:
+    """IblPrecompute::compute (IblPrecompute.cpp:75-561): irradiance 32^2, prefilter 128^2 with all mips, BRDF LUT 512^2."""
+
+    @staticmethod
+    def compute(ctx: Context, env_cube: torch.Tensor, irradiance_size: int = 32, prefilter_size: int = 128,
+                brdf_lut_size: int = 512) -> IblResult:
+        if env_cube.dtype != torch.float32 or env_cube.dim() != 4 or env_cube.shape[0] != 6 or env_cube.shape[3] != 4 \
+                or env_cube.shape[1] != env_cube.shape[2] or not env_cube.is_cuda:
+            raise ValueError("env_cube must be a CUDA float32 [6, S, S, 4] tensor (RGBA32F)")
+        cube = env_cube.contiguous()
+        lib = ctx.lib
+        irr = torch.empty((6, irradiance_size, irradiance_size, 4), dtype=torch.int16, device=ctx.device)
+        pre = torch.empty(int(lib.vkr_ibl_prefilter_texels(prefilter_size)) * 4, dtype=torch.int16, device=ctx.device)
+        lut = torch.empty((brdf_lut_size, brdf_lut_size, 2), dtype=torch.int16, device=ctx.device)
+        _check(ctx.handle, lib.vkr_ibl_compute(ctx.handle, cube.data_ptr(), cube.shape[1], irr.data_ptr(), irradiance_size,
+                                               pre.data_ptr(), prefilter_size, lut.data_ptr(), brdf_lut_size, ctx.stream()),
+               "vkr_ibl_compute")
+        return IblResult(irr, pre, prefilter_size, lut)
+
+
 @dataclass
 class RenderStats:            # RenderPass.h:12-36 (only the field this path fills)
     rtaoMs: float = 0.0

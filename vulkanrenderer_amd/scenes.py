@@ -427,6 +427,34 @@ def make_draw_model(n_nodes: int, n_meshes: int, n_materials: int = 64, seed: in
     return {"node_parent": parent, "node_local": local, "slots": slots, "mesh_infos": infos, "mesh_bounds": bounds}
 
 
+def make_sky_hdr(width: int = 1024, height: int = 512, seed: int = 11, sun_peak: float = 3.0e4) -> np.ndarray:
+    """A synthetic HDR equirect (RGBA32F [H, W, 4], row 0 = zenith) standing in for the reference's .hdr sky: horizon
+    gradient, ground, a small very bright sun, soft clouds.  Dynamic range like an outdoor RGBE image, kept below the
+    fp16 maximum so prefilter mip 0 stays finite."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(height, dtype=np.float64) + 0.5) / height
+    u = (np.arange(width, dtype=np.float64) + 0.5) / width
+    lat = (0.5 - v)[:, None] * np.pi                    # +pi/2 at row 0
+    lon = (u[None, :] - 0.5) * 2.0 * np.pi
+    d = np.stack([np.cos(lat) * np.cos(lon), np.sin(lat) * np.ones_like(lon), np.cos(lat) * np.sin(lon)], axis=-1)
+    up = np.clip(d[..., 1], 0.0, 1.0)
+    sky = np.stack([0.25 + 0.35 * (1 - up) ** 3, 0.45 + 0.35 * (1 - up) ** 3, 0.9 + 0.1 * (1 - up) ** 3], axis=-1)
+    ground = np.array([0.18, 0.15, 0.12])
+    img = np.where(d[..., 1:2] >= 0.0, sky, ground * (0.6 + 0.4 * np.clip(-d[..., 1:2] * 4, 0, 1)))
+    sun = np.array([0.35, 0.62, -0.70]); sun /= np.linalg.norm(sun)
+    cosang = np.clip(d @ sun, -1.0, 1.0)
+    img = img + sun_peak * np.exp(-((1.0 - cosang) / 2.0e-4)) [..., None] * np.array([1.0, 0.93, 0.82])
+    img = img + 4.0 * np.exp(-((1.0 - cosang) / 2.0e-2))[..., None] * np.array([1.0, 0.9, 0.7])
+    clouds = np.zeros((height, width))
+    for k in range(1, 6):
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        clouds += np.sin(k * 3 * lon + ph[0]) * np.sin(k * 5 * lat + ph[1]) / k
+    img = img + (np.clip(clouds, 0, None) * up)[..., None] * 0.6
+    out = np.ones((height, width, 4), dtype=np.float32)
+    out[..., :3] = img.astype(np.float32)
+    return out
+
+
 def make_bistro_class(seed: int = 0xB1572026) -> SceneData:
     return make_street_scene(seed, 1.0, "bistro-class")
 
