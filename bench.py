@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "c0", "c2", "c3", "c4"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "c0", "c1", "c2", "c3", "c4"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip per-kernel timing / counters")
     return ap.parse_args()
@@ -101,6 +101,75 @@ def cpu_baseline(scene, wl, ubos, gb0_depth, gb0_normal, target_seconds):
 def log(msg):
     if os.environ.get("VKR_BENCH_VERBOSE"):
         print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - T_START:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def main_c1(args):
+    """Workload c1 (BASELINE configs[1]): the IBL runtime precompute at the reference's sizes --
+    HDR equirect -> 512^2 RGBA32F env cube (EquirectToCubemap::convert), then IblPrecompute::compute: 32^2 irradiance
+    (252 x 63 samples/texel), 128^2 GGX prefilter with all 8 mips (1024 samples/texel; shading uses mips 0..4), 512^2
+    BRDF LUT (1024 samples/texel).  One-shot work, not sharded: single GPU."""
+    from vulkanrenderer_amd import Context, EquirectToCubemap, IblPrecompute, make_sky_hdr
+    torch.cuda.set_device(0)
+    K, Wu = args.steps, args.warmup
+    ctx = Context(64, 64, 0)
+    sky_np = make_sky_hdr(2048, 1024)
+    sky = torch.from_numpy(sky_np).to(ctx.device)
+    ENV, IRR, PRE, LUT = 512, 32, 128, 512
+
+    def step():
+        cube = EquirectToCubemap.convert(ctx, sky, ENV)
+        return cube, IblPrecompute.compute(ctx, cube, IRR, PRE, LUT)
+
+    for _ in range(Wu):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        cube, res = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib, h, st = ctx.lib, ctx.handle, ctx.stream()
+    pre_texels = int(lib.vkr_ibl_prefilter_texels(PRE))
+    t_eq = np.mean([event_time_ms(lambda: EquirectToCubemap.convert(ctx, sky, ENV), None) for _ in range(5)])
+    t_irr = np.mean([event_time_ms(lambda: lib.vkr_ibl_irradiance(h, cube.data_ptr(), ENV, res.irradiance.data_ptr(), IRR, st), None) for _ in range(5)])
+    t_pre = np.mean([event_time_ms(lambda: lib.vkr_ibl_prefilter(h, cube.data_ptr(), ENV, res.prefilter.data_ptr(), PRE, st), None) for _ in range(5)])
+    t_lut = np.mean([event_time_ms(lambda: lib.vkr_ibl_brdf_lut(h, res.brdf_lut.data_ptr(), LUT, st), None) for _ in range(5)])
+    samples = {"equirect": 6 * ENV * ENV, "irradiance": 6 * IRR * IRR * 252 * 63, "prefilter": pre_texels * 1024,
+               "brdf_lut": LUT * LUT * 1024}
+    total_samples = sum(samples.values())
+    # dominant kernel by time; algorithmic bytes: 64 B of texels per bilinear cube sample (4 x RGBA32F) + 8 B per output texel
+    times = {"k_ibl_irradiance": t_irr, "k_ibl_prefilter (8 mips)": t_pre, "k_ibl_brdf": t_lut, "k_ibl_equirect": t_eq}
+    dom = max(times, key=times.get)
+    alg = {"k_ibl_irradiance": samples["irradiance"] * 64.0 + 6 * IRR * IRR * 8.0,
+           "k_ibl_prefilter (8 mips)": samples["prefilter"] * 64.0 + pre_texels * 8.0,
+           "k_ibl_brdf": LUT * LUT * 4.0, "k_ibl_equirect": samples["equirect"] * (64.0 + 16.0)}[dom]
+    achieved = alg / (times[dom] * 1e-3) / 1e9
+    compulsory = 6 * ENV * ENV * 16.0
+    out = {
+        "metric": "IBL precompute Msamples/s (environment/BRDF samples integrated / wall time of equirect->cube + IblPrecompute::compute)",
+        "value": total_samples * K / elapsed / 1e6, "unit": "Msamples/s", "n_gpus": 1, "steps": K, "warmup": Wu,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c1: HDR equirect 2048x1024 -> {ENV}^2 env cube, {IRR}^2 irradiance, {PRE}^2 GGX prefilter x 8 mips, {LUT}^2 BRDF LUT",
+                   "samples_per_step": total_samples, "parallelism": "single"},
+        "kernels": {"equirect_ms": float(t_eq), "irradiance_ms": float(t_irr), "prefilter_ms": float(t_pre), "brdf_lut_ms": float(t_lut)},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": float(times[dom]),
+                     "algorithmic_bytes_per_launch": alg, "compulsory_bytes_per_launch": compulsory,
+                     "note": "algorithmic = 64 B of RGBA32F texels per bilinear cube sample; the 25 MB environment cube is read from HBM once and then "
+                             "served by L2 / Infinity Cache, so the figure is cache bandwidth, not HBM traffic: these kernels are ALU/latency bound"},
+    }
+    if args.cpu_seconds > 0:
+        from oracle import oracle
+        t1 = time.perf_counter()
+        c_np = oracle.ibl_equirect_to_cube(sky_np, ENV)
+        oracle.ibl_irradiance(c_np, IRR, 0)
+        oracle.ibl_prefilter(c_np, PRE, 0)
+        oracle.ibl_brdf_lut(LUT)
+        t_cpu = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": total_samples / t_cpu / 1e6, "unit": "Msamples/s", "cores": oracle.max_threads(), "kind": "port",
+                               "sample": "one full precompute of the same workload (oracle, the shaders' running-sum order)"}
+    print(json.dumps(out))
 
 
 def main_c2(args):
@@ -177,6 +246,8 @@ def main_c2(args):
 
 def main():
     args = parse_args()
+    if args.workload == "c1":
+        return main_c1(args)
     if args.workload == "c2":
         return main_c2(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
