@@ -31,11 +31,12 @@ class Mesh:
     vertices: np.ndarray        # (V, 15) float32, reference Vertex layout
     indices: np.ndarray         # (I,) uint32, mesh-local
     material_index: int
+    keep_normals: bool = False  # True: vertices[:, 3:6] already holds the file's NORMAL attribute
 
     def __post_init__(self):
         # area-weighted vertex normals, as a glTF exporter would have written them (shared vertices come out smooth)
         v, idx = self.vertices, self.indices.reshape(-1, 3)
-        if len(idx) == 0:
+        if len(idx) == 0 or self.keep_normals:
             return
         p = v[:, :3].astype(np.float64)
         fn = np.cross(p[idx[:, 1]] - p[idx[:, 0]], p[idx[:, 2]] - p[idx[:, 0]])
@@ -453,6 +454,32 @@ def make_sky_hdr(width: int = 1024, height: int = 512, seed: int = 11, sun_peak:
     out = np.ones((height, width, 4), dtype=np.float32)
     out[..., :3] = img.astype(np.float32)
     return out
+
+
+def scene_from_gltf_arrays(positions, normals, uvs, indices, node_local_col_major, name="gltf",
+                           scale: float = 1.0, translate=(0.0, 0.0, 0.0)) -> SceneData:
+    """One-mesh, one-node glTF (decoded arrays, e.g. tests/golden/viking_room_mesh.npz) as a SceneData: the instance
+    transform is modelMatrix * node local matrix (Renderer::rebuildRayTracingInstances, Renderer.cpp:503-527) with
+    modelMatrix = translate * uniform scale."""
+    v = np.zeros((len(positions), VERTEX_FLOATS), dtype=np.float32)
+    v[:, 0:3] = positions
+    v[:, 3:6] = normals
+    v[:, 6:9] = 1.0
+    v[:, 9:11] = uvs
+    mesh = Mesh(v, np.ascontiguousarray(indices, dtype=np.uint32), 0, keep_normals=True)
+    local = np.asarray(node_local_col_major, dtype=np.float64).reshape(4, 4).T
+    model = np.eye(4)
+    model[:3, :3] *= scale
+    model[:3, 3] = translate
+    world = (model @ local).astype(np.float32)
+    sc = SceneData([mesh], [Material()], np.zeros(1, dtype=np.uint32), world[:3, :4].reshape(1, 12).copy(), name)
+    w = positions @ world[:3, :3].T + world[:3, 3]
+    lo, hi = w.min(axis=0), w.max(axis=0)
+    c, r = (lo + hi) * 0.5, float(np.linalg.norm(hi - lo)) * 0.5
+    sc.cameras = [(tuple(c + np.array([r * 1.1, r * 0.7, r * 1.2])), tuple(c)),
+                  (tuple(c + np.array([-r * 0.9, r * 0.5, r * 1.3])), tuple(c)),
+                  (tuple(c + np.array([r * 0.2, r * 1.4, -r * 0.6])), tuple(c))]
+    return sc
 
 
 def make_bistro_class(seed: int = 0xB1572026) -> SceneData:
