@@ -74,6 +74,52 @@ private:
     vkr_ctx* ctx_;
 };
 
+// FrameManager's shared-opaque indirect path (FrameManager.cpp:81-175): buildSharedDrawSlots once per model,
+// prepareSharedOpaqueIndirect per frame; drawData / indirect commands are DEVICE buffers of maxDraws entries.
+class HipSharedOpaqueIndirect {
+public:
+    explicit HipSharedOpaqueIndirect(HipContext& c) : ctx_(c.get()) {}
+    void buildSharedDrawSlots(const vkr_indirect_desc& desc)
+    {
+        check(ctx_, vkr_indirect_upload(ctx_, &desc), "vkr_indirect_upload");
+        maxDraws_ = desc.max_draws < 1u ? 1u : desc.max_draws;
+        spans_.assign(desc.slot_count ? desc.slot_count : 1u, vkr_bucket_span{});
+    }
+    // viewProj == nullptr: the reference as it is (no culling)
+    void prepareSharedOpaqueIndirect(const float modelMatrix[16], const float* viewProj, float* drawData,
+                                     vkr_draw_indexed_indirect_command* commands, void* stream = nullptr)
+    {
+        check(ctx_, vkr_indirect_prepare(ctx_, modelMatrix, viewProj, drawData, commands, maxDraws_, stream), "vkr_indirect_prepare");
+        uint32_t n = 0;
+        check(ctx_, vkr_indirect_result(ctx_, &drawCount_, spans_.data(), (uint32_t)spans_.size(), &n, stream), "vkr_indirect_result");
+        spanCount_ = n < spans_.size() ? n : (uint32_t)spans_.size();
+    }
+    uint32_t getSharedOpaqueDrawCount() const { return drawCount_; }
+    const vkr_bucket_span* getSharedOpaqueBucketSpans() const { return spans_.data(); }
+    uint32_t getSharedOpaqueBucketSpanCount() const { return spanCount_; }
+
+private:
+    vkr_ctx* ctx_;
+    uint32_t maxDraws_ = 1, drawCount_ = 0, spanCount_ = 0;
+    std::vector<vkr_bucket_span> spans_;
+};
+
+// EquirectToCubemap::convert + IblPrecompute::compute (EquirectToCubemap.h, IblPrecompute.h) over caller-owned device arrays.
+struct HipIblPrecompute {
+    static void convert(HipContext& c, const float* equirect, uint32_t width, uint32_t height, float* envCube,
+                        uint32_t cubeSize = 512, void* stream = nullptr)
+    {
+        check(c.get(), vkr_ibl_equirect_to_cube(c.get(), equirect, width, height, envCube, cubeSize, stream), "vkr_ibl_equirect_to_cube");
+    }
+    static void compute(HipContext& c, const float* envCube, uint32_t envSize, uint16_t* irradiance, uint16_t* prefilter,
+                        uint16_t* brdfLut, uint32_t irradianceSize = 32, uint32_t prefilterSize = 128,
+                        uint32_t brdfLutSize = 512, void* stream = nullptr)
+    {
+        check(c.get(), vkr_ibl_compute(c.get(), envCube, envSize, irradiance, irradianceSize, prefilter, prefilterSize,
+                                       brdfLut, brdfLutSize, stream), "vkr_ibl_compute");
+    }
+};
+
 // What RtaoComputePass pulls from FrameManager getters each frame (RtaoComputePass.cpp:289-368), as one struct the
 // host fills: the UBO it already wrote (FrameManager.cpp:448-511) and the device pointers of the interop images.
 struct RtaoFrameInputs {

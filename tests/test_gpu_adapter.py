@@ -58,3 +58,50 @@ def test_cpp_adapter_matches_python_host(tmp_path):
     assert want.view(np.float16).min() < 0.9
     assert np.array_equal(got, want)
     ctx.close()
+
+
+def test_cpp_indirect_wrapper_matches_python_host(tmp_path):
+    """HipSharedOpaqueIndirect (include/vkr_pass.hpp) == SharedOpaqueIndirect (python) == oracle, with culling."""
+    from oracle import oracle
+    from vulkanrenderer_amd.scenes import make_draw_model, look_at_rh, perspective_rh_zo_yflip, col_major
+    m = make_draw_model(20000, 300, 32, seed=31, invalid_fraction=0.02)
+    model = col_major(np.array([[0.8, 0, 0.6, 3], [0, 1.25, 0, -2], [-0.6, 0, 0.8, 7], [0, 0, 0, 1]], dtype=np.float32))
+    vp = col_major((perspective_rh_zo_yflip(55.0, 16 / 9, 0.1, 400.0) @ look_at_rh((0, 8, 70), (0, 0, 0))).astype(np.float32))
+    max_draws = 9000
+    blob = tmp_path / "ind.bin"
+    with open(blob, "wb") as f:
+        f.write(np.array([len(m["node_parent"]), len(m["slots"]), len(m["mesh_infos"]), max_draws, 1], dtype=np.uint32).tobytes())
+        for a in (m["node_parent"], m["node_local"], m["slots"], m["mesh_infos"], m["mesh_bounds"], model, vp):
+            f.write(np.ascontiguousarray(a).tobytes())
+    out = tmp_path / "ind_out.bin"
+    r = subprocess.run([DEMO, "indirect", str(blob), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("ok indirect"), r.stdout + r.stderr
+    raw = np.fromfile(out, dtype=np.uint8)
+    n, sc = np.frombuffer(raw[:8], dtype=np.uint32)
+    wn, wdd, wcm, wsp = oracle.prepare_indirect(m["node_parent"], m["node_local"], oracle.sort_draw_slots(m["slots"]),
+                                                m["mesh_infos"], model, max_draws, view_proj=vp, mesh_bounds=m["mesh_bounds"])
+    assert (n, sc) == (wn, len(wsp)) and 0 < n <= max_draws
+    o = 8
+    assert raw[o:o + 16 * sc].tobytes() == wsp.tobytes(); o += 16 * sc
+    assert raw[o:o + 20 * n].tobytes() == wcm.tobytes(); o += 20 * n
+    assert raw[o:o + 64 * n].tobytes() == wdd.tobytes() and o + 64 * n == raw.size
+
+
+def test_cpp_ibl_wrapper_matches_oracle(tmp_path):
+    """HipIblPrecompute (include/vkr_pass.hpp): convert + compute == oracle (two-level order), small sizes."""
+    from oracle import oracle
+    from vulkanrenderer_amd.scenes import make_sky_hdr
+    sky = make_sky_hdr(128, 64)
+    ENV, IRR, PRE, LUT = 32, 4, 8, 32
+    blob = tmp_path / "ibl.bin"
+    with open(blob, "wb") as f:
+        f.write(np.array([128, 64, ENV, IRR, PRE, LUT], dtype=np.uint32).tobytes())
+        f.write(sky.tobytes())
+    out = tmp_path / "ibl_out.bin"
+    r = subprocess.run([DEMO, "ibl", str(blob), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("ok ibl"), r.stdout + r.stderr
+    got = np.fromfile(out, dtype=np.uint16)
+    cube = oracle.ibl_equirect_to_cube(sky, ENV)
+    want = np.concatenate([oracle.ibl_irradiance(cube, IRR, 1).reshape(-1), oracle.ibl_prefilter(cube, PRE, 1).reshape(-1),
+                           oracle.ibl_brdf_lut(LUT).reshape(-1)])
+    assert got.tobytes() == want.tobytes()

@@ -96,9 +96,104 @@ private:
 
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
+// `indirect in.bin out.bin`: FrameManager::buildSharedDrawSlots + prepareSharedOpaqueIndirect through the C++ wrapper.
+// in:  u32 {nodes, slots, meshes, maxDraws, cull}, i32 parent[nodes], f32 local[nodes*16], slots, infos, f32 bounds[meshes*6],
+//      f32 model[16], f32 viewProj[16]      out: u32 drawCount, u32 spanCount, spans, commands[drawCount], drawData[drawCount*16]
+static int run_indirect(const char* in_path, const char* out_path)
+{
+    FILE* f = fopen(in_path, "rb");
+    if (!f) { perror(in_path); return 66; }
+    uint32_t h[5];
+    if (fread(h, 4, 5, f) != 5) return 65;
+    const uint32_t nn = h[0], ns = h[1], nm = h[2], maxDraws = h[3], cull = h[4];
+    std::vector<int32_t> parent(nn);
+    std::vector<float> local((size_t)nn * 16), bounds((size_t)nm * 6);
+    std::vector<vkr_draw_slot> slots(ns);
+    std::vector<vkr_mesh_draw_info> infos(nm);
+    float model[16], vp[16];
+    if (fread(parent.data(), 4, nn, f) != nn || fread(local.data(), 4, local.size(), f) != local.size() ||
+        fread(slots.data(), sizeof(vkr_draw_slot), ns, f) != ns || fread(infos.data(), sizeof(vkr_mesh_draw_info), nm, f) != nm ||
+        fread(bounds.data(), 4, bounds.size(), f) != bounds.size() || fread(model, 4, 16, f) != 16 || fread(vp, 4, 16, f) != 16) return 65;
+    fclose(f);
+    try {
+        vkr::HipContext context(0, 16, 16);
+        vkr::HipSharedOpaqueIndirect ind(context);
+        vkr_indirect_desc d{parent.data(), local.data(), nn, slots.data(), ns, infos.data(), nm, bounds.data(), maxDraws};
+        ind.buildSharedDrawSlots(d);
+        float* drawData = nullptr;
+        vkr_draw_indexed_indirect_command* cmds = nullptr;
+        const uint32_t cap = maxDraws < 1u ? 1u : maxDraws;
+        HIP_CHECK(hipMalloc((void**)&drawData, (size_t)cap * 64));
+        HIP_CHECK(hipMalloc((void**)&cmds, (size_t)cap * sizeof(vkr_draw_indexed_indirect_command)));
+        ind.prepareSharedOpaqueIndirect(model, cull ? vp : nullptr, drawData, cmds);
+        const uint32_t n = ind.getSharedOpaqueDrawCount(), sc = ind.getSharedOpaqueBucketSpanCount();
+        std::vector<vkr_draw_indexed_indirect_command> hc(n);
+        std::vector<float> hd((size_t)n * 16);
+        if (n) {
+            HIP_CHECK(hipMemcpy(hc.data(), cmds, (size_t)n * sizeof(hc[0]), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(hd.data(), drawData, (size_t)n * 64, hipMemcpyDeviceToHost));
+        }
+        FILE* o = fopen(out_path, "wb");
+        if (!o) { perror(out_path); return 73; }
+        fwrite(&n, 4, 1, o); fwrite(&sc, 4, 1, o);
+        fwrite(ind.getSharedOpaqueBucketSpans(), sizeof(vkr_bucket_span), sc, o);
+        fwrite(hc.data(), sizeof(hc[0]), n, o); fwrite(hd.data(), 4, hd.size(), o);
+        fclose(o);
+        (void)hipFree(drawData); (void)hipFree(cmds);
+        printf("ok indirect draws=%u spans=%u\n", n, sc);
+        return 0;
+    } catch (const std::exception& ex) {
+        fprintf(stderr, "error: %s\n", ex.what());
+        return 1;
+    }
+}
+
+// `ibl in.bin out.bin`: EquirectToCubemap::convert + IblPrecompute::compute through the C++ wrapper.
+// in: u32 {W, H, env, irr, pre, lut}, f32 equirect[H*W*4]     out: irradiance | prefilter | lut (raw halves)
+static int run_ibl(const char* in_path, const char* out_path)
+{
+    FILE* f = fopen(in_path, "rb");
+    if (!f) { perror(in_path); return 66; }
+    uint32_t h[6];
+    if (fread(h, 4, 6, f) != 6) return 65;
+    std::vector<float> eq((size_t)h[0] * h[1] * 4);
+    if (fread(eq.data(), 4, eq.size(), f) != eq.size()) return 65;
+    fclose(f);
+    try {
+        vkr::HipContext context(0, 16, 16);
+        const size_t nIrr = (size_t)6 * h[3] * h[3] * 4, nPre = vkr_ibl_prefilter_texels(h[4]) * 4, nLut = (size_t)h[5] * h[5] * 2;
+        float *dEq = nullptr, *dCube = nullptr;
+        uint16_t* dOut = nullptr;
+        HIP_CHECK(hipMalloc((void**)&dEq, eq.size() * 4));
+        HIP_CHECK(hipMalloc((void**)&dCube, (size_t)6 * h[2] * h[2] * 16));
+        HIP_CHECK(hipMalloc((void**)&dOut, (nIrr + nPre + nLut) * 2));
+        HIP_CHECK(hipMemcpy(dEq, eq.data(), eq.size() * 4, hipMemcpyHostToDevice));
+        vkr::HipIblPrecompute::convert(context, dEq, h[0], h[1], dCube, h[2]);
+        vkr::HipIblPrecompute::compute(context, dCube, h[2], dOut, dOut + nIrr, dOut + nIrr + nPre, h[3], h[4], h[5]);
+        vkr::check(context.get(), vkr_sync(context.get(), nullptr), "vkr_sync");
+        std::vector<uint16_t> out(nIrr + nPre + nLut);
+        HIP_CHECK(hipMemcpy(out.data(), dOut, out.size() * 2, hipMemcpyDeviceToHost));
+        FILE* o = fopen(out_path, "wb");
+        if (!o) { perror(out_path); return 73; }
+        fwrite(out.data(), 2, out.size(), o);
+        fclose(o);
+        (void)hipFree(dEq); (void)hipFree(dCube); (void)hipFree(dOut);
+        bool threw = false;   // sizes that are not powers of two surface as the adapter's exception
+        try { vkr::HipIblPrecompute::convert(context, dEq, h[0], h[1], dCube, 24); } catch (const std::runtime_error&) { threw = true; }
+        if (!threw) { fprintf(stderr, "expected a bad cube size to throw\n"); return 3; }
+        printf("ok ibl halves=%zu\n", out.size());
+        return 0;
+    } catch (const std::exception& ex) {
+        fprintf(stderr, "error: %s\n", ex.what());
+        return 1;
+    }
+}
+
 int main(int argc, char** argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 64; }
+    if (argc >= 4 && std::strcmp(argv[1], "indirect") == 0) return run_indirect(argv[2], argv[3]);
+    if (argc >= 4 && std::strcmp(argv[1], "ibl") == 0) return run_ibl(argv[2], argv[3]);
+    if (argc < 3) { fprintf(stderr, "usage: %s scene.bin out.bin | indirect in.bin out.bin | ibl in.bin out.bin\n", argv[0]); return 64; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 66; }
     uint32_t hdr[7];
