@@ -310,27 +310,41 @@ def main():
     log("G-buffers ready")
     rpass = RtaoComputePass(ctx, gbs[0], atrous_iterations=iters)
     y0, y1 = bands.band_rows(H, n, rank)
-    if n > 1:
-        rpass.band = (y0, y1)
     shadows = ShadowRays(ctx, gbs[0]) if sun_samples > 0 else None
     hb = bands.band_height(H, n)
-    packed = torch.zeros((bands.PLANES, hb, W), dtype=torch.int16, device=dev)
-    gathered = torch.zeros((n, bands.PLANES, hb, W), dtype=torch.int16, device=dev)
+    # N > 1: two-phase schedule.  K1 on interleaved 8-row stripes (evens out the scene-dependent traversal cost and
+    # needs no halo re-trace), all-gather of the history stripes, A-Trous + sun shadows on contiguous bands (their halo
+    # rows come from the gathered history), all-gather of [rtao_full | sun].
+    plan = bands.StripePlan(H, n, dev) if n > 1 else None
+    hist_send = torch.zeros((plan.slot_rows, W), dtype=torch.int16, device=dev) if n > 1 else None
+    hist_recv = torch.zeros((n, plan.slot_rows, W), dtype=torch.int16, device=dev) if n > 1 else None
+    packed = torch.zeros((2, hb, W), dtype=torch.int16, device=dev)
+    gathered = torch.zeros((n, 2, hb, W), dtype=torch.int16, device=dev)
     sun16 = torch.zeros((H, W), dtype=torch.float16, device=dev)
 
     def step(i):
         rpass.gbuffer = gbs[i]
-        rpass.execute(PassExecuteContext(ubo=ubos[i]))
+        if n == 1:
+            rpass.execute(PassExecuteContext(ubo=ubos[i]))
+            if shadows is not None:
+                shadows.gb = gbs[i]
+                shadows.sun(ubos[i])
+            return
+        rpass.traceStripes(ubos[i], rank, n)
+        hc = rpass.historyCurr()
+        plan.pack(hc, rank, hist_send)
+        bands.all_gather_bytes(hist_send, hist_recv)
+        plan.unpack(hist_recv, hc)
+        rpass.denoiseBand(ubos[i], y0, y1)
+        planes = [rpass.rtao_full]
         if shadows is not None:
             shadows.gb = gbs[i]
             shadows.sun(ubos[i], rows=(y0, y1))
-        if n > 1:
-            # one fused all-gather per frame: [history band | rtao_full band | sun band]
             sun16[y0:y1].copy_(shadows.sun_vis[y0:y1])
-            hist = rpass.image(0)
-            bands.pack_band([hist, rpass.rtao_full, sun16.view(torch.int16)], H, n, rank, packed)
-            bands.all_gather_frame(packed, gathered)
-            bands.unpack_frame(gathered, [hist, rpass.rtao_full, sun16.view(torch.int16)], H, n)
+            planes.append(sun16.view(torch.int16))
+        bands.pack_band(planes, H, n, rank, packed)
+        bands.all_gather_frame(packed, gathered)
+        bands.unpack_frame(gathered, planes, H, n)
 
     for i in range(Wu):
         step(i)
@@ -377,7 +391,7 @@ def main():
         "scaling": "strong" if n > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{wl_name}: {scene.name} {W}x{H}, {rays} AO rays/px + temporal + {iters} A-Trous iters"
                                + (f" + {sun_samples} sun-disc shadow rays/px" if sun_samples else "")
-                               + (f", row-band sharded over {n} GPUs + 1 RCCL all-gather/frame" if n > 1 else ""),
+                               + (f", sharded over {n} GPUs (K1: interleaved 8-row stripes, A-Trous/sun: row bands) + 2 RCCL all-gathers/frame" if n > 1 else ""),
                    "triangles": info.triangle_count, "instances": int(len(scene.instance_mesh)),
                    "bvh_levels": info.height, "bvh_nodes": info.node_count, "binary_height": info.binary_height, "lbvh_build_ms": build_ms,
                    "rays_per_frame": total_rays / K, "parallelism": f"rowband{n}" if n > 1 else "single"},

@@ -223,6 +223,18 @@ VKR_API int vkr_rtao_execute(vkr_ctx* ctx, const vkr_rtao_frame_io* io, void* st
  * vkr_rtao_execute.  The caller all-gathers the bands (history via vkr_rtao_image(ctx, 0)) before the next frame. */
 VKR_API int vkr_rtao_execute_band(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t y0, uint32_t y1, void* stream);
 
+/* Two-phase sharding for multi-GPU (no reference counterpart).  Phase 1: dispatchTrace on the 8-row stripes
+ * s = rank, rank + nranks, rank + 2*nranks, ... (stripe s = rows [8s, 8s+8)): interleaving evens out the per-row cost
+ * of the traversal.  The caller then all-gathers history[curr] (vkr_rtao_image after the frame, or which = 0 of the
+ * ping-pong BEFORE end-of-frame: see vkr_rtao_history_curr) so that every rank holds all rows.  Phase 2:
+ * vkr_rtao_denoise_band runs A-Trous x N + upsample for rows [y0, y1) -- its halo rows are read from the gathered
+ * history instead of being re-traced -- and ends the frame like vkr_rtao_execute.  y0 == y1 is allowed (a rank
+ * without rows still flips its frame index).  Bit-identical to vkr_rtao_execute on the same inputs. */
+VKR_API int vkr_rtao_trace_stripes(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t rank, uint32_t nranks, void* stream);
+VKR_API int vkr_rtao_denoise_band(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t y0, uint32_t y1, void* stream);
+/* history[curr] of the frame in flight (the image dispatchTrace writes; device pointer, R16F W*H). */
+VKR_API int vkr_rtao_history_curr(vkr_ctx* ctx, uint16_t** out);
+
 /* The three dispatches, individually callable (RtaoComputePass.cpp:503-517, 519-554, 556-571).
  * Push constants {width,height,step,iteration} (RtaoComputePass.h:21-26) become arguments. */
 VKR_API int vkr_rtao_trace(vkr_ctx* ctx, const vkr_rtao_frame_io* io, void* stream);

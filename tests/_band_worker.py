@@ -35,8 +35,30 @@ def band_frame(osc, ubo, depth, normal, hist_prev, y0, y1, iters):
     return cur, lo(halo_all), hi(halo_all), full
 
 
+def stripe_frame(osc, ubo, depth, normal, hist_prev, hist_curr, rank, world, plan, send, recv, y0, y1, iters):
+    """The two-phase schedule of bench.py (vkr_rtao_trace_stripes -> gather history -> vkr_rtao_denoise_band) on the
+    oracle.  hist_curr is completed in place; returns rtao_full with rows [y0, y1) filled."""
+    Hh, Ww = depth.shape
+    total = (Hh + bands.STRIPE - 1) // bands.STRIPE
+    for s in range(rank, total, world):                    # dispatchTrace on this rank's stripes only
+        a, b = s * bands.STRIPE, min(Hh, (s + 1) * bands.STRIPE)
+        hist_curr[a:b] = osc.trace(ubo, depth, hist_prev, a, b)[a:b]
+    t = torch.from_numpy(hist_curr.view(np.int16))
+    plan.pack(t, rank, send)
+    bands.all_gather_bytes(send, recv)
+    plan.unpack(recv, t)
+    lo = lambda h: max(0, y0 - h)                   # noqa: E731
+    hi = lambda h: min(Hh, y1 + h)                  # noqa: E731
+    src = hist_curr
+    for i in range(iters):
+        halo_out = 2 * ((1 << iters) - (1 << (i + 1)))
+        src = O.atrous(ubo, 1 << i, src, depth, normal, lo(halo_out), hi(halo_out))
+    return O.upsample(ubo, src, normal)
+
+
 def main():
     out_dir = sys.argv[1]
+    schedule = sys.argv[2] if len(sys.argv) > 2 else "bands"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     O.set_threads(2)
@@ -51,6 +73,9 @@ def main():
     hb = bands.band_height(H, world)
     packed = torch.zeros((bands.PLANES, hb, W), dtype=torch.int16)
     gathered = torch.zeros((world, bands.PLANES, hb, W), dtype=torch.int16)
+    plan = bands.StripePlan(H, world)
+    h_send = torch.zeros((plan.slot_rows, W), dtype=torch.int16)
+    h_recv = torch.zeros((world, plan.slot_rows, W), dtype=torch.int16)
     ok = True
     for f, (eye, tgt) in enumerate(camera_path(scene, FRAMES)):
         ubo = fs.update(eye, tgt)
@@ -59,8 +84,13 @@ def main():
         want_hist = ref.hist[ref.last_curr]
         want_sun = osc.shadow_sun(wp, ng, valid, FrameState.sun_dir_to_light(ubo), 0.01, 4).astype(np.float16)
 
-        cur, lo, hi, full = band_frame(osc, ubo, depth, normal, hist[parity ^ 1], y0, y1, ITERS)
-        hist[parity][lo:hi] = cur[lo:hi]
+        if schedule == "stripes":
+            hist[parity][:] = 0x1234                          # rows of other ranks must arrive through the gather
+            full = stripe_frame(osc, ubo, depth, normal, hist[parity ^ 1], hist[parity], rank, world, plan, h_send, h_recv,
+                                y0, y1, ITERS)
+        else:
+            cur, lo, hi, full = band_frame(osc, ubo, depth, normal, hist[parity ^ 1], y0, y1, ITERS)
+            hist[parity][lo:hi] = cur[lo:hi]
         sun = np.zeros((H, W), dtype=np.float16)
         sun[y0:y1] = osc.shadow_sun(wp[y0:y1], ng[y0:y1], valid[y0:y1], FrameState.sun_dir_to_light(ubo), 0.01,
                                     4).astype(np.float16)

@@ -61,14 +61,31 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_band_schedule_over_gloo_matches_full_frame(world, tmp_path, oracle_mod):
+@pytest.mark.parametrize("H,n", [(37, 2), (37, 3), (2160, 8), (1080, 4), (5, 8), (64, 8), (8, 1)])
+def test_stripe_plan_roundtrip(H, n):
+    """Interleaved 8-row stripes: every image row travels exactly once, ragged ends included."""
+    W = 5
+    plan = bands.StripePlan(H, n)
+    assert plan.slot_rows == bands.stripes_per_rank(H, n) * bands.STRIPE
+    full = torch.arange(H * W, dtype=torch.int32).view(H, W).to(torch.int16)
+    g = torch.zeros((n, plan.slot_rows, W), dtype=torch.int16)
+    owner = (torch.arange(H) // bands.STRIPE) % n
+    for r in range(n):
+        mine = torch.where((owner == r)[:, None], full, torch.full_like(full, -7))     # rank r only has its own rows
+        plan.pack(mine, r, g[r])
+    out = torch.zeros_like(full)
+    plan.unpack(g, out)
+    assert torch.equal(out, full)
+
+
+@pytest.mark.parametrize("world,schedule", [(2, "bands"), (3, "bands"), (2, "stripes"), (3, "stripes")])
+def test_band_schedule_over_gloo_matches_full_frame(world, schedule, tmp_path, oracle_mod):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                OMP_NUM_THREADS="2")
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_band_worker.py"), str(tmp_path)], env=e,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_band_worker.py"), str(tmp_path), schedule], env=e,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:

@@ -259,6 +259,86 @@ def test_band_schedule_equals_full_frame_1080p_8_bands(torch_mod):
     _band_vs_full(make_sponza_class(), 1920, 1080, 8, 4, 8, 2)
 
 
+def _stripes_vs_full(scene, W, H, rays, iters, n, frames, step=0.05, sun_samples=0):
+    """The two-phase schedule bench.py runs for N > 1 (K1 on interleaved 8-row stripes -> gather history -> A-Trous on
+    contiguous bands -> gather rtao_full), emulated with N contexts on one GPU, against one full-frame context."""
+    import torch
+    from vulkanrenderer_amd import FrameState, bands, camera_path
+    from vulkanrenderer_amd.renderer import PassExecuteContext, RtaoComputePass, generate_gbuffer
+    full_ctx, full_rt, full_gb = _ctx(scene, W, H)
+    full_pass = RtaoComputePass(full_ctx, full_gb, atrous_iterations=iters)
+    ranks = []
+    for r in range(n):
+        ctx, rt, gb = _ctx(scene, W, H)
+        ranks.append((ctx, rt, gb, RtaoComputePass(ctx, gb, atrous_iterations=iters)))
+    dev = full_ctx.device
+    plan = bands.StripePlan(H, n, dev)
+    hist_g = torch.zeros((n, plan.slot_rows, W), dtype=torch.int16, device=dev)
+    hb = bands.band_height(H, n)
+    out_g = torch.zeros((n, 1, hb, W), dtype=torch.int16, device=dev)
+    fs = FrameState(W, H, ray_count=rays)
+    for f, (eye, tgt) in enumerate(camera_path(scene, frames, step=step)):
+        ubo = fs.update(eye, tgt)
+        generate_gbuffer(full_ctx, ubo, full_gb)
+        full_pass.execute(PassExecuteContext(ubo=ubo))
+        full_ctx.sync()
+        for r, (ctx, rt, gb, p) in enumerate(ranks):
+            gb.linear_depth.copy_(full_gb.linear_depth)
+            gb.normal.copy_(full_gb.normal)
+            p.historyCurr().fill_(0x1234)                   # rows this rank does not trace must come from the gather
+            p.traceStripes(ubo, r, n)
+            plan.pack(p.historyCurr(), r, hist_g[r])
+        for r, (ctx, rt, gb, p) in enumerate(ranks):
+            plan.unpack(hist_g, p.historyCurr())
+            y0, y1 = bands.band_rows(H, n, r)
+            p.denoiseBand(ubo, y0, y1)
+            bands.pack_band([p.rtao_full], H, n, r, out_g[r])
+        for r, (ctx, rt, gb, p) in enumerate(ranks):
+            bands.unpack_frame(out_g, [p.rtao_full], H, n)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_np_u16(p.image(0)), to_np_u16(full_pass.image(0))), f"frame {f} rank {r} history"
+            assert np.array_equal(to_np_u16(p.rtao_full), to_np_u16(full_pass.rtao_full)), f"frame {f} rank {r} rtao_full"
+    for ctx, *_ in ranks:
+        ctx.close()
+    full_ctx.close()
+
+
+@pytest.mark.parametrize("n,H,iters", [(2, 90, 2), (3, 91, 3), (4, 90, 4), (8, 90, 1), (8, 37, 5), (5, 8, 2)])
+def test_stripe_schedule_equals_full_frame(torch_mod, n, H, iters):
+    from vulkanrenderer_amd import make_street_scene
+    _stripes_vs_full(make_street_scene(21, 0.02, "band"), 160, H, 4, iters, n, 3, step=0.3)
+
+
+def test_stripe_schedule_equals_full_frame_1080p_8_ranks(torch_mod):
+    from vulkanrenderer_amd import make_sponza_class
+    _stripes_vs_full(make_sponza_class(), 1920, 1080, 8, 4, 8, 2)
+
+
+def test_sun_shadows_small_launch_chunks(torch_mod, oracle_mod):
+    """Row-band sized sun-shadow launches pick 64/128-pixel chunks (k_shadow_sun_pkt): same bits as the oracle."""
+    import torch
+    from vulkanrenderer_amd import FrameState, make_street_scene
+    from vulkanrenderer_amd.renderer import GBuffer, ShadowRays, generate_gbuffer
+    scene = make_street_scene(21, 0.02, "band")
+    W, H = 256, 150
+    ctx, rt, gb0 = _ctx(scene, W, H)
+    gb = GBuffer(ctx, with_shading_inputs=True)
+    osc = oracle_mod.OracleScene(scene)
+    fs = FrameState(W, H, ray_count=4, sun_samples=8)
+    ubo = fs.update(*scene.cameras[0])
+    generate_gbuffer(ctx, ubo, gb)
+    ctx.sync()
+    wp, ng, valid = gb.world_pos.cpu().numpy(), gb.geom_normal.cpu().numpy(), gb.valid.cpu().numpy()
+    want = osc.shadow_sun(wp, ng, valid, FrameState.sun_dir_to_light(ubo), float(ubo[56]), int(ubo[57]))
+    sh = ShadowRays(ctx, gb)
+    for rows in [(0, H), (10, 11), (40, 97), (H - 3, H)]:      # 38400, 256, 14592, 768 pixels
+        sh.sun_vis.fill_(-1.0)
+        got = sh.sun(ubo, rows=rows).cpu().numpy()
+        assert got[rows[0]:rows[1]].tobytes() == want[rows[0]:rows[1]].tobytes(), rows
+        assert (got[:rows[0]] == -1.0).all() and (got[rows[1]:] == -1.0).all()
+    ctx.close()
+
+
 def test_full_size_properties_1080p(torch_mod):
     """At BASELINE size without the oracle: AO in [0,1], sky pixels exactly 1, a static camera converges
     (|frame k+1 - frame k| shrinks), ray counters consistent with the valid-pixel count."""

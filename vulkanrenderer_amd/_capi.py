@@ -103,6 +103,9 @@ SYMBOLS = {
     "vkr_bvh_download": (C.c_int, [_P, _P, _P]),
     "vkr_rtao_execute": (C.c_int, [_P, C.POINTER(RtaoFrameIO), _P]),
     "vkr_rtao_execute_band": (C.c_int, [_P, C.POINTER(RtaoFrameIO), C.c_uint32, C.c_uint32, _P]),
+    "vkr_rtao_trace_stripes": (C.c_int, [_P, C.POINTER(RtaoFrameIO), C.c_uint32, C.c_uint32, _P]),
+    "vkr_rtao_denoise_band": (C.c_int, [_P, C.POINTER(RtaoFrameIO), C.c_uint32, C.c_uint32, _P]),
+    "vkr_rtao_history_curr": (C.c_int, [_P, C.POINTER(_P)]),
     "vkr_rtao_trace": (C.c_int, [_P, C.POINTER(RtaoFrameIO), _P]),
     "vkr_rtao_atrous": (C.c_int, [_P, C.POINTER(RtaoFrameIO), C.c_uint32, C.c_uint32, _P]),
     "vkr_rtao_upsample": (C.c_int, [_P, C.POINTER(RtaoFrameIO), C.c_uint32, _P]),

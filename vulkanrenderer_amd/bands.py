@@ -70,5 +70,59 @@ def unpack_frame(gathered: torch.Tensor, planes: Sequence[torch.Tensor], H: int,
             p[full_bands * hb:].copy_(gathered[full_bands, k, :rem])
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Two-phase schedule: K1 on interleaved 8-row stripes (stripe s belongs to rank s % n), one all-gather of the history
+# stripes, A-Trous / shadows on contiguous bands, one all-gather of [rtao_full | sun].
+# ---------------------------------------------------------------------------------------------------------------
+STRIPE = 8
+
+
+def stripes_per_rank(H: int, n: int) -> int:
+    """Stripes each rank's gather slot holds (padded: ranks past the ragged end own one stripe less)."""
+    total = (H + STRIPE - 1) // STRIPE
+    return (total + n - 1) // n
+
+
+class StripePlan:
+    """Row bookkeeping of the interleaved-stripe exchange for an (H, W) plane over n ranks.  Rank r owns the rows of
+    stripes r, r+n, ...; every rank's gather slot holds k = stripes_per_rank stripes (ragged ends padded: padded rows
+    are sent as copies of the last image row and dropped on arrival)."""
+
+    def __init__(self, H: int, n: int, device=None):
+        k = stripes_per_rank(H, n)
+        rows = (torch.arange(k)[None, :, None] * n + torch.arange(n)[:, None, None]) * STRIPE + torch.arange(STRIPE)[None, None, :]
+        rows = rows.reshape(n, k * STRIPE)                       # [rank, slot row] -> image row
+        valid = rows < H
+        self.H, self.n, self.k = H, n, k
+        self.slot_rows = k * STRIPE
+        self.rows_clamped = rows.clamp(max=H - 1).to(device)
+        self.src = torch.nonzero(valid.reshape(-1)).squeeze(1).to(device)      # positions in the gathered (n*k*8) rows
+        self.dst = rows.reshape(-1)[valid.reshape(-1)].to(device)               # ... and the image rows they fill
+        assert self.dst.numel() == H and int(self.dst.sort().values.ne(torch.arange(H, device=self.dst.device)).sum()) == 0
+
+    def pack(self, plane: torch.Tensor, r: int, out: torch.Tensor) -> torch.Tensor:
+        """Rank r's rows of plane (H, W) -> out (k*8, W)."""
+        torch.index_select(plane, 0, self.rows_clamped[r], out=out)
+        return out
+
+    def unpack(self, gathered: torch.Tensor, plane: torch.Tensor) -> None:
+        """gathered (n, k*8, W) -> plane (H, W): every row exactly once."""
+        plane.index_copy_(0, self.dst, gathered.view(-1, gathered.shape[-1]).index_select(0, self.src))
+
+
+def all_gather_bytes(send: torch.Tensor, recv: torch.Tensor, group=None) -> torch.Tensor:
+    """recv (n, *send.shape) <- every rank's send; payload as raw bytes (see all_gather_frame)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if send.is_cuda and dist.get_backend(group) == "gloo":
+            h_out = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(h_out.view(-1).view(torch.uint8), send.contiguous().cpu().view(-1).view(torch.uint8), group=group)
+            recv.copy_(h_out)
+            return recv
+        dist.all_gather_into_tensor(recv.view(-1).view(torch.uint8), send.contiguous().view(-1).view(torch.uint8), group=group)
+    else:
+        recv.view(-1)[: send.numel()].copy_(send.reshape(-1))
+    return recv
+
+
 def split_rows(H: int, n: int) -> List[Tuple[int, int]]:
     return [band_rows(H, n, r) for r in range(n)]

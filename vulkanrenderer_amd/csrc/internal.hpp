@@ -48,6 +48,7 @@ struct FrameParams {
     float disocclusionRaw;   // rtaoParams1.z
     float radiusRaw;         // rtaoParams0.z (A-Trous uses max(.,0.01) itself)
     int W, H;
+    int stripeMul;      // K1 tile rows are 8-row stripes y0/8 + k*stripeMul (1 = contiguous rows; N = every N-th stripe)
 };
 
 // inverse of the ordered-uint float encoding used for atomicMin/atomicMax on bounds

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
     const uint32_t tile = blockIdx.x;
     const int lane = threadIdx.x;
     const int px = (int)(tile % tiles_x) * 8 + (lane & 7);
-    const int py = y0 + (int)(tile / tiles_x) * 8 + (lane >> 3);
+    const int py = y0 + (int)(tile / tiles_x) * 8 * fp.stripeMul + (lane >> 3);
     const int W = fp.W, H = fp.H;
     const Img16 depth{depthP, W, H}, histPrev{histPrevP, W, H};
     const int rayCount = fp.rayCount;                                           // :252
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
         if (tile >= n_tiles) break;          // every wave reaches this: the counter only grows
         const int px = (int)(tile % tiles_x) * 8 + (lane & 7);
-        const int py = y0 + (int)(tile / tiles_x) * 8 + (lane >> 3);
+        const int py = y0 + (int)(tile / tiles_x) * 8 * fp.stripeMul + (lane >> 3);
 
         // ------------------------------------------------------------------ phase 1: per pixel
         PixelCtx pc;
@@ -855,7 +855,8 @@ hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* 
                              uint16_t* hist_curr, uint32_t* hit_mask, int y0, int y1, hipStream_t st)
 {
     if (y1 <= y0) return hipSuccess;
-    uint32_t tiles_x = ((uint32_t)fp.W + 7u) / 8u, tiles_y = ((uint32_t)(y1 - y0) + 7u) / 8u;
+    const uint32_t mul = fp.stripeMul > 1 ? (uint32_t)fp.stripeMul : 1u;
+    uint32_t tiles_x = ((uint32_t)fp.W + 7u) / 8u, tiles_y = (((uint32_t)(y1 - y0) + 7u) / 8u + mul - 1u) / mul;
     uint32_t n_tiles = tiles_x * tiles_y;
     SceneDev sc = scene_dev(c);
     hipError_t e;

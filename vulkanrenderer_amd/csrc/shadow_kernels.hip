@@ -505,8 +505,10 @@ __global__ void k_sun_setup(V3 L, float sunRadius, float sampleCountF, SunFrame*
 }
 
 __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs sa, const SunFrame* __restrict__ sf,
-                                                       uint32_t n_chunks, uint32_t* chunk_counter)
+                                                       uint32_t n_chunks, uint32_t pix_per_chunk, uint32_t* chunk_counter)
 {
+    // pix_per_chunk: 64, 128 or 256 (<= SP_PIX).  Small launches (row bands of a sharded frame) use small chunks so that
+    // the persistent waves still get several chunks each; per-pixel results do not depend on it.
     __shared__ uint32_t s_nq[SP_NQ];       // node items: pixel << 22 | node
     __shared__ uint32_t s_lq[KQ_LQ];       // leaf items: leaf reference ...
     __shared__ uint16_t s_lqp[KQ_LQ];      // ... and its pixel
@@ -531,11 +533,11 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
         if (lane == 0) chunk = atomicAdd(chunk_counter, 1u);
         chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
         if (chunk >= n_chunks) break;        // every wave reaches this: the counter only grows
-        const uint32_t pix0 = chunk * (uint32_t)SP_PIX;
+        const uint32_t pix0 = chunk * pix_per_chunk;
 
         // ------------------------------------------------------------------ phase 1: origins
         uint32_t nq = 0, lq = 0;
-        for (int j = 0; j < SP_PIX / 64; ++j) {
+        for (int j = 0; j < (int)(pix_per_chunk / 64u); ++j) {
             const uint32_t p = (uint32_t)j * 64u + (uint32_t)lane;
             const uint32_t i = pix0 + p;
             bool live = false;
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
         }
 
         // ------------------------------------------------------------------ phase 3: per pixel
-        for (int j = 0; j < SP_PIX / 64; ++j) {
+        for (int j = 0; j < (int)(pix_per_chunk / 64u); ++j) {
             const uint32_t p = (uint32_t)j * 64u + (uint32_t)lane;
             const uint32_t i = pix0 + p;
             const uint32_t m = s_mask[p];
@@ -720,15 +722,17 @@ hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const
             if (!c->d_sun_frame.p && (e = c->d_sun_frame.alloc(sizeof(SunFrame))) != hipSuccess) return e;
             SunFrame* sf = (SunFrame*)c->d_sun_frame.p;
             k_sun_setup<<<1, 64, 0, st>>>(sa.L, radius, samples, sf);
-            const uint32_t n_chunks = (count + SP_PIX - 1u) / SP_PIX;
             int per_cu = 0;
             if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) return e;
             if (per_cu < 1) per_cu = 1;
             uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
+            uint32_t pix = (uint32_t)SP_PIX;                      // aim for >= 4 chunks per resident wave
+            while (pix > 64u && (count + pix - 1u) / pix < 4u * blocks) pix >>= 1;
+            const uint32_t n_chunks = (count + pix - 1u) / pix;
             if (blocks > n_chunks) blocks = n_chunks;
             if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(8)) != hipSuccess) return e;
             if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
-            k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, c->d_tile_counter.p);
+            k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, c->d_tile_counter.p);
             return hipGetLastError();
         }
         return shadow_q_launch(c, 0, sa, st);

@@ -81,6 +81,7 @@ FrameParams make_frame_params(const vkr_ctx* c, const float* ubo)
     fp.radiusRaw = ubo[VKR_UBO_RTAO_PARAMS0 + 2];
     fp.W = (int)c->W;
     fp.H = (int)c->H;
+    fp.stripeMul = 1;
     return fp;
 }
 
@@ -696,6 +697,14 @@ int vkr_rtao_image(vkr_ctx* c, uint32_t which, uint16_t** out)
     return VKR_OK;
 }
 
+int vkr_rtao_history_curr(vkr_ctx* c, uint16_t** out)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
+    *out = c->d_hist_img[c->frame_parity].p;
+    return VKR_OK;
+}
+
 int vkr_rtao_trace(vkr_ctx* c, const vkr_rtao_frame_io* io, void* stream)
 {
     if (int rc = check_io(c, io, false, false)) return rc;
@@ -768,6 +777,57 @@ int vkr_rtao_execute_band(vkr_ctx* c, const vkr_rtao_frame_io* io, uint32_t y0, 
     if (!fold_upsample)
         HIP_OR_FAIL(c, rtao_upsample_launch(c, fp.debugMode, c->d_ping[(n - 1u) & 1u].p, io->normal_rgba16f,
                                             io->rtao_full_r16f, (int)y0, (int)y1, st));
+    vkr_rtao_end_frame(c);
+    return VKR_OK;
+}
+
+// Two-phase sharding (multi-GPU, no reference counterpart): K1 on interleaved 8-row stripes, then -- after the caller
+// has all-gathered history[curr] -- A-Trous/upsample on a contiguous band whose halo rows come from the gathered image.
+int vkr_rtao_trace_stripes(vkr_ctx* c, const vkr_rtao_frame_io* io, uint32_t rank, uint32_t nranks, void* stream)
+{
+    if (int rc = check_io(c, io, false, false)) return rc;
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_rtao_trace_stripes before vkr_bvh_build");
+    if (nranks == 0 || rank >= nranks) return fail(c, VKR_ERR_INVALID_ARG, "rank %u of %u", rank, nranks);
+    if (int rc = set_device(c)) return rc;
+    FrameParams fp = make_frame_params(c, io->ubo);
+    fp.stripeMul = (int)nranks;
+    const uint32_t curr = c->frame_parity;
+    const int y0 = (int)(rank * 8u);
+    if (y0 >= (int)c->H) return VKR_OK;                      // more ranks than stripes: nothing to trace
+    HIP_OR_FAIL(c, rtao_trace_launch(c, fp, io->linear_depth_r16f, c->d_hist_img[curr ^ 1u].p, c->d_hist_img[curr].p,
+                                     io->ray_hit_mask, y0, (int)c->H, (hipStream_t)stream));
+    return VKR_OK;
+}
+
+int vkr_rtao_denoise_band(vkr_ctx* c, const vkr_rtao_frame_io* io, uint32_t y0, uint32_t y1, void* stream)
+{
+    if (int rc = check_io(c, io, true, true)) return rc;
+    if (y0 > y1 || y1 > c->H) return fail(c, VKR_ERR_INVALID_ARG, "band [%u,%u) outside image height %u", y0, y1, c->H);
+    if (io->atrous_iterations > 16u) return fail(c, VKR_ERR_INVALID_ARG, "atrous_iterations %u > 16", io->atrous_iterations);
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = (int)c->H;
+    const uint32_t n = io->atrous_iterations < 1u ? 1u : io->atrous_iterations;
+    FrameParams fp = make_frame_params(c, io->ubo);
+    const uint32_t curr = c->frame_parity;
+    if (y0 < y1) {
+        auto lo = [&](long halo) { long v = (long)y0 - halo; return (int)(v < 0 ? 0 : v); };
+        auto hi = [&](long halo) { long v = (long)y1 + halo; return (int)(v > H ? H : v); };
+        const long halo_all = 2L * ((1L << n) - 1L);
+        HIP_OR_FAIL(c, rtao_prep_launch(c, io->linear_depth_r16f, io->normal_rgba16f, lo(halo_all), hi(halo_all), st));
+        const bool fold_upsample = (fp.debugMode != 9u);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint16_t* src = (i == 0) ? c->d_hist_img[curr].p : c->d_ping[(i - 1u) & 1u].p;
+            const long halo_out = 2L * ((1L << n) - (1L << (i + 1)));
+            const bool last = (i + 1 == n);
+            HIP_OR_FAIL(c, rtao_atrous_launch(c, fp.radiusRaw, 1 << i, src, c->d_ping[i & 1u].p,
+                                              (last && fold_upsample) ? io->rtao_full_r16f : nullptr, lo(halo_out),
+                                              hi(halo_out), st));
+        }
+        if (!fold_upsample)
+            HIP_OR_FAIL(c, rtao_upsample_launch(c, fp.debugMode, c->d_ping[(n - 1u) & 1u].p, io->normal_rgba16f,
+                                                io->rtao_full_r16f, (int)y0, (int)y1, st));
+    }
     vkr_rtao_end_frame(c);
     return VKR_OK;
 }

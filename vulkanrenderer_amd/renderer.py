@@ -422,6 +422,24 @@ class RtaoComputePass(RenderPass):
         final_index = (self.iterations - 1) % 2      # RtaoComputePass.cpp:560-561
         _check(c.handle, c.lib.vkr_rtao_upsample(c.handle, C.byref(io), final_index, c.stream()), "vkr_rtao_upsample")
 
+    # two-phase sharding (multi-GPU): K1 on interleaved stripes, gather history, A-Trous on a contiguous band
+    def traceStripes(self, ubo, rank: int, nranks: int):
+        c = self.ctx
+        io = self._io(ubo)
+        _check(c.handle, c.lib.vkr_rtao_trace_stripes(c.handle, C.byref(io), rank, nranks, c.stream()), "vkr_rtao_trace_stripes")
+
+    def denoiseBand(self, ubo, y0: int, y1: int):
+        c = self.ctx
+        io = self._io(ubo)
+        _check(c.handle, c.lib.vkr_rtao_denoise_band(c.handle, C.byref(io), y0, y1, c.stream()), "vkr_rtao_denoise_band")
+
+    def historyCurr(self) -> torch.Tensor:
+        """history[curr] of the frame in flight (what dispatchTrace writes), aliasing the library's memory."""
+        c = self.ctx
+        p = C.c_void_p()
+        _check(c.handle, c.lib.vkr_rtao_history_curr(c.handle, C.byref(p)), "vkr_rtao_history_curr")
+        return _alias_device_memory(p.value, (c.height, c.width), c.device)
+
     def endFrame(self):
         _check(self.ctx.handle, self.ctx.lib.vkr_rtao_end_frame(self.ctx.handle), "vkr_rtao_end_frame")
 
