@@ -562,6 +562,11 @@ __host__ __device__ inline QSliceLayout q_slice_layout(int rayCount)
 #ifndef K1_NQ
 #define K1_NQ 640
 #endif
+// Pixels per work item of k_trace_q: 64 (8x8) or 32 (8x4; lanes 32..63 mirror the pixels of lanes 0..31 and generate
+// the odd rays, lanes 0..31 resolve).  Smaller items shorten the drain of the persistent launch.
+#ifndef K1_TILE_PX
+#define K1_TILE_PX 32
+#endif
 template <bool STATS>
 __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_WAVES, VKR_Q_WAVES))) void k_trace_q(SceneDev sc, FrameParams fp, const uint16_t* depthP,
                                                       const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
@@ -594,8 +599,13 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
         if (lane == 0) tile = atomicAdd(tile_counter, 1u);
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
         if (tile >= n_tiles) break;          // every wave reaches this: the counter only grows
-        const int px = (int)(tile % tiles_x) * 8 + (lane & 7);
-        const int py = y0 + (int)(tile / tiles_x) * 8 * fp.stripeMul + (lane >> 3);
+        constexpr bool HALF = (K1_TILE_PX == 32);
+        const int plane = HALF ? (lane & 31) : lane;          // pixel of the item this lane works on
+        const int half = HALF ? (lane >> 5) : 0;              // which rays it generates (i = half, half + 2, ...)
+        const int trow = (int)(tile / tiles_x);
+        const int px = (int)(tile % tiles_x) * 8 + (plane & 7);
+        const int py = HALF ? y0 + (trow >> 1) * 8 * fp.stripeMul + (trow & 1) * 4 + (plane >> 3)
+                            : y0 + trow * 8 * fp.stripeMul + (plane >> 3);
 
         // ------------------------------------------------------------------ phase 1: per pixel
         PixelCtx pc;
@@ -604,12 +614,13 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
         if (px < W && py < y1) setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);   // :233-235
         const bool valid = pc.valid;
         const float radius = pc.radius;
-        const unsigned long long vmask = __ballot(valid);
+        const unsigned long long vmask = HALF ? (__ballot(valid) & 0xffffffffull) : __ballot(valid);
         const uint32_t nvalid = (uint32_t)__popcll(vmask);
         if (nvalid == 0) continue;   // wave-uniform: nothing to trace, nothing to resolve
-        const uint32_t rank = (uint32_t)__popcll(vmask & lt_mask);
+        const uint32_t rank = (uint32_t)__popcll(vmask & (HALF ? ((1ull << plane) - 1ull) : lt_mask));
+        const bool owner = valid && half == 0;                // the lane that resolves the pixel
         if (valid) {
-            for (int i = 0; i < rayCount; ++i) {                                    // :403-430
+            for (int i = half; i < rayCount; i += (HALF ? 2 : 1)) {                 // :403-430
                 V3 rayOrigin, rayDir;
                 float tMinRay;
                 make_ray(pc, rayCount, i, &rayOrigin, &rayDir, &tMinRay);
@@ -793,7 +804,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
                 for (int i = 0; i < rayCount; ++i) {
                     bool need = false;
                     const uint32_t k = (uint32_t)i * nvalid + rank;
-                    if (valid) {
+                    if (owner) {
                         const float tbv = u2f(s_tbest[k]);
                         const float tmin0 = slice[(size_t)k * 3u].w;
                         need = (tbv < radius) && (tbv <= tmin0 * 1.5f);
@@ -814,7 +825,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
         }
 
         // ------------------------------------------------------------------ phase 3: per pixel resolve + temporal
-        if (valid) {
+        if (owner) {
             float visibility = 0.0f;
             uint32_t mask = 0;
             for (int i = 0; i < rayCount; ++i) {                                    // :431 in ray order
@@ -858,9 +869,11 @@ hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* 
     const uint32_t mul = fp.stripeMul > 1 ? (uint32_t)fp.stripeMul : 1u;
     uint32_t tiles_x = ((uint32_t)fp.W + 7u) / 8u, tiles_y = (((uint32_t)(y1 - y0) + 7u) / 8u + mul - 1u) / mul;
     uint32_t n_tiles = tiles_x * tiles_y;
+    const bool streaming = c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS);
+    if (streaming && K1_TILE_PX == 32) n_tiles *= 2u;            // 8x4 items: two per 8x8 tile row (see k_trace_q)
     SceneDev sc = scene_dev(c);
     hipError_t e;
-    if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
+    if (streaming) {
         // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
         const size_t lds = (size_t)fp.rayCount * 64u * 4u + (size_t)K1_NQ * 4u + (size_t)KQ_LQ * 6u + (size_t)KQ_AQ * 6u;
         int per_cu = 0;
