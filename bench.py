@@ -333,15 +333,16 @@ def main():
         rpass.traceStripes(ubos[i], rank, n)
         hc = rpass.historyCurr()
         plan.pack(hc, rank, hist_send)
-        bands.all_gather_bytes(hist_send, hist_recv)
-        plan.unpack(hist_recv, hc)
-        rpass.denoiseBand(ubos[i], y0, y1)
+        work = bands.all_gather_bytes(hist_send, hist_recv, async_op=True)     # overlaps the sun-shadow kernel below
         planes = [rpass.rtao_full]
         if shadows is not None:
             shadows.gb = gbs[i]
             shadows.sun(ubos[i], rows=(y0, y1))
             sun16[y0:y1].copy_(shadows.sun_vis[y0:y1])
             planes.append(sun16.view(torch.int16))
+        work.wait()
+        plan.unpack(hist_recv, hc)
+        rpass.denoiseBand(ubos[i], y0, y1)
         bands.pack_band(planes, H, n, rank, packed)
         bands.all_gather_frame(packed, gathered)
         bands.unpack_frame(gathered, planes, H, n)

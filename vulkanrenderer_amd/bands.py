@@ -110,18 +110,26 @@ class StripePlan:
         plane.index_copy_(0, self.dst, gathered.view(-1, gathered.shape[-1]).index_select(0, self.src))
 
 
-def all_gather_bytes(send: torch.Tensor, recv: torch.Tensor, group=None) -> torch.Tensor:
-    """recv (n, *send.shape) <- every rank's send; payload as raw bytes (see all_gather_frame)."""
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_gather_bytes(send: torch.Tensor, recv: torch.Tensor, group=None, async_op: bool = False):
+    """recv (n, *send.shape) <- every rank's send; payload as raw bytes (see all_gather_frame).  Returns a handle whose
+    wait() orders the current stream after the collective; with async_op=True (RCCL only) the collective runs on the
+    communicator's stream while the caller keeps enqueuing independent kernels."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if send.is_cuda and dist.get_backend(group) == "gloo":
             h_out = torch.empty(recv.shape, dtype=recv.dtype)
             dist.all_gather_into_tensor(h_out.view(-1).view(torch.uint8), send.contiguous().cpu().view(-1).view(torch.uint8), group=group)
             recv.copy_(h_out)
-            return recv
-        dist.all_gather_into_tensor(recv.view(-1).view(torch.uint8), send.contiguous().view(-1).view(torch.uint8), group=group)
-    else:
-        recv.view(-1)[: send.numel()].copy_(send.reshape(-1))
-    return recv
+            return _Done()
+        work = dist.all_gather_into_tensor(recv.view(-1).view(torch.uint8), send.contiguous().view(-1).view(torch.uint8),
+                                           group=group, async_op=async_op)
+        return work if async_op and work is not None else _Done()
+    recv.view(-1)[: send.numel()].copy_(send.reshape(-1))
+    return _Done()
 
 
 def split_rows(H: int, n: int) -> List[Tuple[int, int]]:
