@@ -314,6 +314,59 @@ def test_stripe_schedule_equals_full_frame_1080p_8_ranks(torch_mod):
     _stripes_vs_full(make_sponza_class(), 1920, 1080, 8, 4, 8, 2)
 
 
+def test_c4_full_size_sharded_equals_unsharded(torch_mod):
+    """BASELINE configs[4] at full size (bistro-class, 3840x2160, 8 AO rays + 16 sun rays per pixel, 4 A-Trous
+    iterations) over 8 ranks: the size-independent property 'sharded == unsharded, bit for bit' for history, rtao_full
+    and the sun visibility, two frames (the second one reprojects the gathered history)."""
+    import torch
+    from vulkanrenderer_amd import FrameState, bands, camera_path, make_bistro_class
+    from vulkanrenderer_amd.renderer import GBuffer, PassExecuteContext, RtaoComputePass, ShadowRays, generate_gbuffer
+    scene = make_bistro_class()
+    W, H, n = 3840, 2160, 8
+    full_ctx, _, _ = _ctx(scene, W, H)
+    full_gb = GBuffer(full_ctx, with_shading_inputs=True)
+    full_pass = RtaoComputePass(full_ctx, full_gb, atrous_iterations=4)
+    full_sh = ShadowRays(full_ctx, full_gb)
+    # one sharded context reused for every rank (8 more 4K contexts would only cost memory): its history image is
+    # reset to the previous gathered history before each rank's turn
+    ctx, _, _ = _ctx(scene, W, H)
+    p = RtaoComputePass(ctx, full_gb, atrous_iterations=4)
+    sh = ShadowRays(ctx, full_gb)
+    plan = bands.StripePlan(H, n, full_ctx.device)
+    hist_g = torch.zeros((n, plan.slot_rows, W), dtype=torch.int16, device=full_ctx.device)
+    fs = FrameState(W, H, ray_count=8, sun_samples=16)
+    for f, (eye, tgt) in enumerate(camera_path(scene, 2)):
+        ubo = fs.update(eye, tgt)
+        generate_gbuffer(full_ctx, ubo, full_gb)
+        full_pass.execute(PassExecuteContext(ubo=ubo))
+        want_sun = full_sh.sun(ubo).clone()
+        full_ctx.sync()
+        want_hist, want_full = full_pass.image(0).clone(), full_pass.rtao_full.clone()
+        for r in range(n):                                   # phase 1 of every rank
+            p.historyCurr().fill_(0x1234)
+            p.traceStripes(ubo, r, n)
+            plan.pack(p.historyCurr(), r, hist_g[r])
+        plan.unpack(hist_g, p.historyCurr())                 # all-gather #1
+        assert torch.equal(p.historyCurr(), want_hist), f"frame {f}: gathered history"
+        got_full = torch.zeros_like(want_full)
+        got_sun = torch.full_like(want_sun, -1.0)
+        for r in range(n):                                   # phase 2 of every rank (denoise_band ends the frame:
+            y0, y1 = bands.band_rows(H, n, r)                #  undo the flip for all but the last rank)
+            p.denoiseBand(ubo, y0, y1)
+            got_full[y0:y1] = p.rtao_full[y0:y1]
+            got_sun[y0:y1] = sh.sun(ubo, rows=(y0, y1))[y0:y1]
+            if r != n - 1:
+                p.endFrame()                                 # flips back: frame_parity ^= 1 twice
+        torch.cuda.synchronize()
+        assert torch.equal(got_full, want_full), f"frame {f}: rtao_full"
+        assert torch.equal(got_sun, want_sun), f"frame {f}: sun"
+        assert torch.equal(p.image(0), want_hist)
+        ao = want_full.view(torch.float16).float()
+        assert 0.3 < float(ao.mean()) < 1.0 and float(ao.min()) < 0.5
+    ctx.close()
+    full_ctx.close()
+
+
 def test_sun_shadows_small_launch_chunks(torch_mod, oracle_mod):
     """Row-band sized sun-shadow launches pick 64/128-pixel chunks (k_shadow_sun_pkt): same bits as the oracle."""
     import torch

@@ -77,6 +77,21 @@ def test_deep_and_interleaved_hierarchies(ctx):
     run_both(ctx, m2, MODEL, 1 << 16, vp=view_proj())
 
 
+def test_many_buckets(ctx):
+    """More than 4096 (doubleSided, material) buckets: the span ranking leaves its LDS staging; more than 8192 is refused."""
+    from vulkanrenderer_amd import SharedOpaqueIndirect
+    m = make_draw_model(40000, 9000, 8000, seed=23)
+    keys = len(np.unique(m["slots"]["mat_index"].astype(np.uint64) * 2 + m["slots"]["double_sided"]))
+    assert 4096 < keys <= 8192
+    run_both(ctx, m, MODEL, 1 << 17)
+    run_both(ctx, m, MODEL, 1 << 17, vp=view_proj())
+    big = make_draw_model(60000, 30000, 30000, seed=24)
+    assert len(np.unique(big["slots"]["mat_index"])) > 8192
+    ib = SharedOpaqueIndirect(ctx)
+    with pytest.raises(RuntimeError, match="buckets"):
+        ib.buildSharedDrawSlots(big["node_parent"], big["node_local"], big["slots"], big["mesh_infos"], 1 << 17)
+
+
 def test_invalid_slots_are_skipped(ctx):
     m = make_draw_model(9000, 100, 16, seed=11, invalid_fraction=0.07)
     ib, n = run_both(ctx, m, I16, 1 << 20)

@@ -534,6 +534,8 @@ int vkr_indirect_upload(vkr_ctx* c, const vkr_indirect_desc* d)
     uint32_t keys = 0;
     for (uint32_t i = 0; i < d->slot_count; ++i)
         if (i == 0 || c->h_ib_slots[i].w != c->h_ib_slots[i - 1].w || c->h_ib_slots[i].z != c->h_ib_slots[i - 1].z) ++keys;
+    // the span pass ranks the bucket heads in one block (quadratic in the bucket count): bound it
+    if (keys > 8192u) return fail(c, VKR_ERR_LIMIT, "%u (doubleSided, material) buckets; at most 8192 are supported", keys);
     c->ib_node_count = d->node_count; c->ib_slot_count = d->slot_count; c->ib_mesh_count = d->mesh_count;
     c->ib_max_draws = d->max_draws < 1u ? 1u : d->max_draws;      // std::max(1u, MAX_DRAWS), FrameManager.cpp:24
     c->ib_span_capacity = keys ? keys : 1u;
