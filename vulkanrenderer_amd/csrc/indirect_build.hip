@@ -165,10 +165,10 @@ __global__ __launch_bounds__(1024) void k_ib_scan_tiles(uint32_t* tile_count, ui
     if (threadIdx.x == 1023) *total = s_part[1023];
 }
 
-// pass 3: rank the survivors inside each tile and emit (:141-151).  keys[drawId] = doubleSided << 31 | matIndex.
+// pass 3: rank the survivors inside each tile and emit (:141-151)
 __global__ __launch_bounds__(256) void k_ib_emit(const DrawSlotDev* slots, uint32_t n_slots, const uint8_t* flags,
                                                  const uint32_t* tile_base, const MeshInfoDev* infos, const float4* world,
-                                                 uint32_t max_draws, float4* draw_data, DrawCmdDev* commands, uint64_t* keys)
+                                                 uint32_t max_draws, float4* draw_data, DrawCmdDev* commands)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_run;
@@ -194,7 +194,6 @@ __global__ __launch_bounds__(256) void k_ib_emit(const DrawSlotDev* slots, uint3
             c.index_count = info.index_count; c.instance_count = 1; c.first_index = info.first_index;
             c.vertex_offset = (int32_t)info.vertex_offset; c.first_instance = id; // :143-148
             commands[id] = c;
-            keys[id] = ((uint64_t)(s.ds ? 1u : 0u) << 32) | s.mat;
         }
         __syncthreads();
         if (threadIdx.x == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -202,47 +201,81 @@ __global__ __launch_bounds__(256) void k_ib_emit(const DrawSlotDev* slots, uint3
     }
 }
 
-// bucket spans (:154-172): a span starts wherever the key changes along the emitted commands
-__global__ __launch_bounds__(256) void k_ib_span_heads(const uint64_t* keys, const uint32_t* total, uint32_t max_draws,
-                                                       uint32_t* span_count, uint32_t* head_pos, uint32_t span_capacity)
+// bucket spans (:154-172).  The buckets are the runs of equal (doubleSided, matIndex) in the sorted slot list, known
+// since the upload: seg_begin[s] = first slot of run s, seg_begin[n_segs] = n_slots.  The span of run s is
+// [rank(seg_begin[s]), rank(seg_begin[s+1])) clipped to the draw count, with rank(x) = survivors before slot x --
+// no atomics, no sorting.  One wave per boundary: rank = exclusive tile base + the tile's flag bytes before x.
+__global__ __launch_bounds__(256) void k_ib_seg_rank(const uint32_t* seg_begin, uint32_t n_bounds, uint32_t n_slots,
+                                                     const uint32_t* tile_base, const uint8_t* flags, const uint32_t* total,
+                                                     uint32_t* seg_rank)
 {
-    const uint32_t n = *total < max_draws ? *total : max_draws;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    if (i == 0 || keys[i] != keys[i - 1]) {
-        const uint32_t s = atomicAdd(span_count, 1u);
-        if (s < span_capacity) head_pos[s] = i;
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= n_bounds) return;                                   // whole waves leave together
+    const uint32_t x = seg_begin[b];
+    uint32_t rank;
+    if (x >= n_slots) rank = *total;
+    else {
+        const uint32_t t0 = (x / (uint32_t)IB_TILE) * (uint32_t)IB_TILE;
+        // the tile's flag bytes (0/1) as 32-bit words: 8 independent loads per lane, bytes at or past x masked off
+        const uint32_t* fw = (const uint32_t*)(flags + t0);      // t0 is a multiple of 2048 and flags is hipMalloc-aligned
+        const uint32_t nb = x - t0;                              // bytes that count
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)IB_TILE / 256u; ++k) {
+            const uint32_t w = k * 64u + (uint32_t)lane, byte0 = 4u * w;
+            if (byte0 < nb) {
+                const uint32_t keep = nb - byte0;                // 1..: bytes of this word that count
+                uint32_t v = fw[w];
+                if (keep < 4u) v &= (1u << (8u * keep)) - 1u;
+                cnt += (uint32_t)__popc(v);
+            }
+        }
+        cnt = wave_incl_scan(cnt);
+        rank = tile_base[x / (uint32_t)IB_TILE] + (uint32_t)__builtin_amdgcn_readlane((int)cnt, 63);
     }
+    if (lane == 0) seg_rank[b] = rank;
 }
 
-// spans are few (one per (doubleSided, material) key): one block ranks the head positions and closes the ranges.
-// Up to IB_SPAN_LDS heads are staged in LDS; beyond that the ranking reads them from global memory.
-constexpr uint32_t IB_SPAN_LDS = 4096;
-__global__ __launch_bounds__(256) void k_ib_span_emit(const uint64_t* keys, const uint32_t* total, uint32_t max_draws,
-                                                      const uint32_t* span_count, const uint32_t* head_pos, uint32_t span_capacity,
-                                                      SpanDev* spans)
+// one block: spans of the non-empty runs, in run order (:169-171 pushes only drawCount > 0)
+__global__ __launch_bounds__(1024) void k_ib_span_emit(const uint32_t* seg_begin, const DrawSlotDev* slots, uint32_t n_segs,
+                                                       const uint32_t* seg_rank, const uint32_t* total, uint32_t max_draws,
+                                                       uint32_t* span_count, SpanDev* spans, uint32_t span_capacity)
 {
-    __shared__ uint32_t s_head[IB_SPAN_LDS];
+    __shared__ uint32_t s_scan[1024];
+    __shared__ uint32_t s_carry;
     const uint32_t n = *total < max_draws ? *total : max_draws;
-    const uint32_t ns = *span_count < span_capacity ? *span_count : span_capacity;
-    const bool staged = ns <= IB_SPAN_LDS;
-    if (staged) {
-        for (uint32_t a = threadIdx.x; a < ns; a += 256u) s_head[a] = head_pos[a];
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_segs; base += 1024u) {
+        const uint32_t sgm = base + threadIdx.x;
+        uint32_t first = 0, count = 0;
+        if (sgm < n_segs) {
+            const uint32_t r0 = seg_rank[sgm], r1 = seg_rank[sgm + 1];
+            first = r0 < n ? r0 : n;
+            count = (r1 < n ? r1 : n) - first;
+        }
+        const uint32_t flag = count ? 1u : 0u;
+        s_scan[threadIdx.x] = flag;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t v = (threadIdx.x >= (uint32_t)off) ? s_scan[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t pos = s_carry + s_scan[threadIdx.x] - flag;
+        if (flag && pos < span_capacity) {
+            const DrawSlotDev sl = slots[seg_begin[sgm]];
+            SpanDev sp;
+            sp.ds = sl.ds ? 1u : 0u; sp.mat = sl.mat; sp.first = first; sp.count = count;
+            spans[pos] = sp;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry += s_scan[1023];
         __syncthreads();
     }
-    for (uint32_t a = threadIdx.x; a < ns; a += 256u) {
-        const uint32_t pos = staged ? s_head[a] : head_pos[a];
-        uint32_t rank = 0, next = n;
-        for (uint32_t b = 0; b < ns; ++b) {
-            const uint32_t q = staged ? s_head[b] : head_pos[b];
-            rank += (q < pos) ? 1u : 0u;
-            if (q > pos && q < next) next = q;
-        }
-        const uint64_t key = keys[pos];
-        SpanDev sp;
-        sp.ds = (uint32_t)(key >> 32); sp.mat = (uint32_t)key; sp.first = pos; sp.count = next - pos;
-        spans[rank] = sp;
-    }
+    if (threadIdx.x == 0) *span_count = s_carry;
 }
 
 #define IB_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
@@ -273,12 +306,13 @@ hipError_t indirect_prepare_launch(vkr_ctx* c, const float model[16], const floa
     k_ib_scan_tiles<<<1, 1024, 0, st>>>(c->d_ib_tile.p, tiles, c->d_ib_counters.p);
     k_ib_emit<<<tiles, 256, 0, st>>>((const DrawSlotDev*)c->d_ib_slots.p, ns, c->d_ib_flags.p, c->d_ib_tile.p,
                                      (const MeshInfoDev*)c->d_ib_infos.p, c->d_ib_world.p, c->ib_max_draws, draw_data,
-                                     (DrawCmdDev*)commands, c->d_ib_keys.p);
-    const uint32_t cap = ns < c->ib_max_draws ? ns : c->ib_max_draws;
-    k_ib_span_heads<<<(cap + 255u) / 256u, 256, 0, st>>>(c->d_ib_keys.p, c->d_ib_counters.p, c->ib_max_draws,
-                                                         c->d_ib_counters.p + 1, c->d_ib_heads.p, c->ib_span_capacity);
-    k_ib_span_emit<<<1, 256, 0, st>>>(c->d_ib_keys.p, c->d_ib_counters.p, c->ib_max_draws, c->d_ib_counters.p + 1,
-                                      c->d_ib_heads.p, c->ib_span_capacity, (SpanDev*)c->d_ib_spans.p);
+                                     (DrawCmdDev*)commands);
+    const uint32_t nseg = c->ib_seg_count;
+    k_ib_seg_rank<<<(nseg + 1u + 3u) / 4u, 256, 0, st>>>(c->d_ib_seg_begin.p, nseg + 1u, ns, c->d_ib_tile.p, c->d_ib_flags.p,
+                                                        c->d_ib_counters.p, c->d_ib_seg_rank.p);
+    k_ib_span_emit<<<1, 1024, 0, st>>>(c->d_ib_seg_begin.p, (const DrawSlotDev*)c->d_ib_slots.p, nseg, c->d_ib_seg_rank.p,
+                                       c->d_ib_counters.p, c->ib_max_draws, c->d_ib_counters.p + 1, (SpanDev*)c->d_ib_spans.p,
+                                       c->ib_span_capacity);
     return hipGetLastError();
 }
 

@@ -104,8 +104,9 @@ struct vkr_ctx {
     vkr::DevBuf<uint32_t> d_ib_infos;             // MeshDrawInfo, 3 words per mesh
     vkr::DevBuf<float> d_ib_bounds;               // optional mesh AABBs, 6 floats per mesh
     vkr::DevBuf<uint8_t> d_ib_flags;
-    vkr::DevBuf<uint32_t> d_ib_tile, d_ib_counters, d_ib_heads;
-    vkr::DevBuf<uint64_t> d_ib_keys;
+    vkr::DevBuf<uint32_t> d_ib_tile, d_ib_counters;
+    vkr::DevBuf<uint32_t> d_ib_seg_begin, d_ib_seg_rank;   // runs of equal (doubleSided, matIndex): first slot (+ n_slots), rank
+    uint32_t ib_seg_count = 0;
     vkr::DevBuf<uint4> d_ib_spans;
     std::vector<uint4> h_ib_slots;
     vkr::DevBuf<uint32_t> d_ib_order;             // nodes grouped by hierarchy level (level-per-launch world matrices)

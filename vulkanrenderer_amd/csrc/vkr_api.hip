@@ -162,7 +162,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_sun_frame.release();
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
     c->d_ib_infos.release(); c->d_ib_bounds.release(); c->d_ib_flags.release(); c->d_ib_tile.release();
-    c->d_ib_counters.release(); c->d_ib_heads.release(); c->d_ib_keys.release(); c->d_ib_spans.release();
+    c->d_ib_counters.release(); c->d_ib_seg_begin.release(); c->d_ib_seg_rank.release(); c->d_ib_spans.release();
     c->d_ib_order.release(); c->d_ibl_tables.release();
     delete c;
 }
@@ -531,11 +531,13 @@ int vkr_indirect_upload(vkr_ctx* c, const vkr_indirect_desc* d)
         if (a.z != b.z) return a.z < b.z;
         return a.y < b.y;
     });
-    uint32_t keys = 0;
+    // runs of equal (doubleSided, matIndex) = the buckets of prepareSharedOpaqueIndirect's std::map (:135-136,149)
+    std::vector<uint32_t> seg_begin;
     for (uint32_t i = 0; i < d->slot_count; ++i)
-        if (i == 0 || c->h_ib_slots[i].w != c->h_ib_slots[i - 1].w || c->h_ib_slots[i].z != c->h_ib_slots[i - 1].z) ++keys;
-    // the span pass ranks the bucket heads in one block (quadratic in the bucket count): bound it
-    if (keys > 8192u) return fail(c, VKR_ERR_LIMIT, "%u (doubleSided, material) buckets; at most 8192 are supported", keys);
+        if (i == 0 || c->h_ib_slots[i].w != c->h_ib_slots[i - 1].w || c->h_ib_slots[i].z != c->h_ib_slots[i - 1].z) seg_begin.push_back(i);
+    const uint32_t keys = (uint32_t)seg_begin.size();
+    seg_begin.push_back(d->slot_count);
+    c->ib_seg_count = keys;
     c->ib_node_count = d->node_count; c->ib_slot_count = d->slot_count; c->ib_mesh_count = d->mesh_count;
     c->ib_max_draws = d->max_draws < 1u ? 1u : d->max_draws;      // std::max(1u, MAX_DRAWS), FrameManager.cpp:24
     c->ib_span_capacity = keys ? keys : 1u;
@@ -545,12 +547,13 @@ int vkr_indirect_upload(vkr_ctx* c, const vkr_indirect_desc* d)
     HIP_OR_FAIL(c, c->d_ib_world.alloc((size_t)(d->node_count ? d->node_count : 1) * 4));
     HIP_OR_FAIL(c, c->d_ib_slots.alloc(d->slot_count ? d->slot_count : 1));
     HIP_OR_FAIL(c, c->d_ib_infos.alloc((size_t)(d->mesh_count ? d->mesh_count : 1) * 3));
-    HIP_OR_FAIL(c, c->d_ib_flags.alloc(d->slot_count ? d->slot_count : 1));
+    HIP_OR_FAIL(c, c->d_ib_flags.alloc((size_t)d->slot_count + 4));   // k_ib_seg_rank reads whole 32-bit words
     HIP_OR_FAIL(c, c->d_ib_tile.alloc(tiles ? tiles : 1));
     HIP_OR_FAIL(c, c->d_ib_counters.alloc(2));
-    HIP_OR_FAIL(c, c->d_ib_heads.alloc(c->ib_span_capacity));
+    HIP_OR_FAIL(c, c->d_ib_seg_begin.alloc(seg_begin.size()));
+    HIP_OR_FAIL(c, c->d_ib_seg_rank.alloc(seg_begin.size()));
+    HIP_OR_FAIL(c, hipMemcpy(c->d_ib_seg_begin.p, seg_begin.data(), seg_begin.size() * 4, hipMemcpyHostToDevice));
     HIP_OR_FAIL(c, c->d_ib_spans.alloc(c->ib_span_capacity));
-    HIP_OR_FAIL(c, c->d_ib_keys.alloc(d->slot_count ? d->slot_count : 1));
     HIP_OR_FAIL(c, hipMemset(c->d_ib_counters.p, 0, 8));
     HIP_OR_FAIL(c, c->d_ib_order.alloc(order.empty() ? 1 : order.size()));
     if (!order.empty()) HIP_OR_FAIL(c, hipMemcpy(c->d_ib_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice));
