@@ -28,7 +28,10 @@ constexpr int VKR_LDS_STACK = 12;    // entries per lane kept in LDS (2 dwords e
 constexpr int VKR_MAX_STACK = 96;    // hard cap; the host checks 3*levels+1 against it after every build
 constexpr int VKR_TRACE_BLOCK = 256;
 constexpr int VKR_GRAPH_MAX_DEPTH = 64;   // scene-graph depth accepted by vkr_hierarchy_upload
-constexpr int VKR_LEAF_MAX = 4;      // triangles per leaf (encoding allows 8)
+#ifndef VKR_LEAF_MAX_N
+#define VKR_LEAF_MAX_N 2
+#endif
+constexpr int VKR_LEAF_MAX = VKR_LEAF_MAX_N;      // triangles per leaf (encoding allows 8); measured 1/2/3/4/6: 2 is best for K1, 1-2 for the sun packets
 constexpr uint32_t VKR_CHILD_NONE = 0x7fffffffu;
 #ifndef VKR_LEAF_VOTE
 #define VKR_LEAF_VOTE 1   // K1 runs a triangle step when n_leaf * VKR_LEAF_VOTE >= n_node * VKR_LEAF_VOTE_DEN
