@@ -82,6 +82,20 @@ static int sah_rec(Tree& t, int lo, int hi)   // [lo, hi)
         if (mid == lo || mid == hi) mid = (lo + hi) >> 1; }
     int l = sah_rec(t, lo, mid), r = sah_rec(t, mid, hi); t.n[id].l = l; t.n[id].r = r; return id;
 }
+// hybrid: LBVH on top, every maximal subtree with <= K triangles rebuilt top-down by (binned) SAH over its own
+// contiguous Morton range -- ranges stay contiguous, so the rest of an LBVH pipeline is untouched
+static int hybrid_rec(Tree& out, const Tree& lb, int n, int K)
+{
+    const BNode& b = lb.n[n];
+    if (b.count <= K) return sah_rec(out, b.first, b.first + b.count);
+    int id = (int)out.n.size(); out.n.emplace_back();
+    int l = hybrid_rec(out, lb, b.l, K), r = hybrid_rec(out, lb, b.r, K);
+    out.n[id].l = l; out.n[id].r = r; out.n[id].first = b.first; out.n[id].count = b.count;
+    out.n[id].box = out.n[l].box; out.n[id].box.grow(out.n[r].box);
+    return id;
+}
+static Tree build_hybrid(int K) { Tree lb = build_lbvh(); Tree t; t.order = lb.order; t.n.reserve(2 * T.size()); t.root = hybrid_rec(t, lb, lb.root, K); return t; }
+
 static Tree build_sah() { Tree t; t.order.resize(T.size()); for (size_t i = 0; i < T.size(); ++i) t.order[i] = (int)i; t.n.reserve(2 * T.size()); t.root = sah_rec(t, 0, (int)T.size()); return t; }
 
 // PLOC over Morton-sorted leaves; leaf order is rebuilt by DFS afterwards
@@ -116,7 +130,8 @@ static Tree build_ploc(int radius)
     return t;
 }
 
-// 4-ary collapse: open largest-area child with > 4 tris, up to twice
+static int LEAFMAX = 4;
+// 4-ary collapse: open largest-area child with > LEAFMAX tris, up to twice
 struct WNode { Box cb[4]; int ref[4]; int nch; };   // ref >= 0 wide node, < 0 leaf ~(binary node)
 struct Wide { std::vector<WNode> w; const Tree* t; };
 static Wide collapse(const Tree& t)
@@ -124,14 +139,14 @@ static Wide collapse(const Tree& t)
     Wide W; W.t = &t; std::vector<int> bin{t.root}; W.w.emplace_back();
     for (size_t wi = 0; wi < bin.size(); ++wi) {
         int b = bin[wi]; std::vector<int> ch;
-        if (t.n[b].count <= 4 || t.n[b].l < 0) ch = {b};
+        if (t.n[b].count <= LEAFMAX || t.n[b].l < 0) ch = {b};
         else { ch = {t.n[b].l, t.n[b].r};
             for (int k = 0; k < 2; ++k) { int bi = -1; float ba = -1;
-                for (size_t c = 0; c < ch.size(); ++c) if (t.n[ch[c]].count > 4 && t.n[ch[c]].l >= 0 && t.n[ch[c]].box.area() > ba) { ba = t.n[ch[c]].box.area(); bi = (int)c; }
+                for (size_t c = 0; c < ch.size(); ++c) if (t.n[ch[c]].count > LEAFMAX && t.n[ch[c]].l >= 0 && t.n[ch[c]].box.area() > ba) { ba = t.n[ch[c]].box.area(); bi = (int)c; }
                 if (bi < 0) break; int o = ch[bi]; ch[bi] = t.n[o].l; ch.push_back(t.n[o].r); } }
         WNode wn; wn.nch = (int)ch.size();
         for (int c = 0; c < wn.nch; ++c) { wn.cb[c] = t.n[ch[c]].box;
-            if (t.n[ch[c]].count <= 4 || t.n[ch[c]].l < 0) wn.ref[c] = ~ch[c];
+            if (t.n[ch[c]].count <= LEAFMAX || t.n[ch[c]].l < 0) wn.ref[c] = ~ch[c];
             else { wn.ref[c] = (int)bin.size(); bin.push_back(ch[c]); W.w.emplace_back(); } }
         W.w[wi] = wn; }
     return W;
@@ -171,9 +186,14 @@ int main(int argc, char** argv)
         if (nn.y < 0) nn = nn * -1.f; V3 dd; do { dd = {U(rng) * 2 - 1, U(rng) * 2 - 1, U(rng) * 2 - 1}; } while (dot(dd, dd) > 1 || dot(dd, dd) < 1e-4f); dd = dd * (1.f / std::sqrt(dot(dd, dd))); if (dot(dd, nn) < 0) dd = dd * -1.f;
         ro[i] = p + nn * 1e-3f; rd[i] = dd; }
     float radius = argc > 2 ? atof(argv[2]) : 1.2f;
+    if (argc > 3) LEAFMAX = atoi(argv[3]);
     auto eval = [&](const char* name, const Tree& t) { Wide W = collapse(t); uint64_t nv = 0, tt = 0; for (int i = 0; i < NR; ++i) trace(W, ro[i], rd[i], radius, nv, tt);
         printf("%-10s binary SAH %.1f  wide nodes %zu  nodes/ray %.2f  tris/ray %.2f\n", name, sah_cost(t), W.w.size(), (double)nv / NR, (double)tt / NR); fflush(stdout); };
     { Tree t = build_lbvh(); eval("lbvh", t); }
+    { Tree t = build_hybrid(16); eval("hyb16", t); }
+    { Tree t = build_hybrid(64); eval("hyb64", t); }
+    { Tree t = build_hybrid(256); eval("hyb256", t); }
+    { Tree t = build_hybrid(4096); eval("hyb4096", t); }
     { Tree t = build_ploc(8); eval("ploc r8", t); }
     { Tree t = build_ploc(25); eval("ploc r25", t); }
     { Tree t = build_sah(); eval("sah16", t); }
