@@ -96,6 +96,42 @@ static int hybrid_rec(Tree& out, const Tree& lb, int n, int K)
 }
 static Tree build_hybrid(int K) { Tree lb = build_lbvh(); Tree t; t.order = lb.order; t.n.reserve(2 * T.size()); t.root = hybrid_rec(t, lb, lb.root, K); return t; }
 
+// hybrid 2: LBVH on top, every maximal subtree with <= K triangles rebuilt by PLOC over its own Morton range (the
+// block-local form a GPU would run in LDS); leaf order inside the range is the DFS order of the rebuilt subtree
+static int ploc_range(Tree& out, int lo, int hi, int radius)     // [lo, hi) of out.order; returns root, reorders the range
+{
+    std::vector<int> cl, tri_of; int base = (int)out.n.size();
+    for (int i = lo; i < hi; ++i) { out.n.emplace_back(); out.n.back().box = TB[out.order[i]]; out.n.back().count = 1; cl.push_back((int)out.n.size() - 1); }
+    std::vector<int> leaf_tri(out.order.begin() + lo, out.order.begin() + hi);
+    while (cl.size() > 1) { int m = (int)cl.size(); std::vector<int> nn(m);
+        for (int i = 0; i < m; ++i) { float best = 1e30f; int bj = -1;
+            for (int j = std::max(0, i - radius); j <= std::min(m - 1, i + radius); ++j) { if (j == i) continue; Box b = out.n[cl[i]].box; b.grow(out.n[cl[j]].box); float a = b.area(); if (a < best) { best = a; bj = j; } }
+            nn[i] = bj; }
+        std::vector<int> next;
+        for (int i = 0; i < m; ++i) { int j = nn[i];
+            if (nn[j] == i) { if (i < j) { int id = (int)out.n.size(); out.n.emplace_back(); out.n[id].l = cl[i]; out.n[id].r = cl[j]; out.n[id].box = out.n[cl[i]].box; out.n[id].box.grow(out.n[cl[j]].box); out.n[id].count = out.n[cl[i]].count + out.n[cl[j]].count; next.push_back(id); } }
+            else next.push_back(cl[i]); }
+        cl.swap(next); }
+    // DFS order -> first/count, reorder the range
+    int root = cl[0], pos = lo; std::vector<std::pair<int, int>> st{{root, 0}};
+    while (!st.empty()) { auto [n, ph] = st.back(); st.pop_back();
+        if (out.n[n].l < 0) { out.n[n].first = pos; out.order[pos++] = leaf_tri[n - base]; continue; }
+        if (ph == 0) { st.push_back({n, 1}); st.push_back({out.n[n].r, 0}); st.push_back({out.n[n].l, 0}); }
+        else out.n[n].first = out.n[out.n[n].l].first; }
+    return root;
+}
+static int hybrid2_rec(Tree& out, const Tree& lb, int n, int K, int radius)
+{
+    const BNode& b = lb.n[n];
+    if (b.count <= K) return ploc_range(out, b.first, b.first + b.count, radius);
+    int id = (int)out.n.size(); out.n.emplace_back();
+    int l = hybrid2_rec(out, lb, b.l, K, radius), r = hybrid2_rec(out, lb, b.r, K, radius);
+    out.n[id].l = l; out.n[id].r = r; out.n[id].first = b.first; out.n[id].count = b.count;
+    out.n[id].box = out.n[l].box; out.n[id].box.grow(out.n[r].box);
+    return id;
+}
+static Tree build_hybrid2(int K, int radius) { Tree lb = build_lbvh(); Tree t; t.order = lb.order; t.n.reserve(3 * T.size()); t.root = hybrid2_rec(t, lb, lb.root, K, radius); return t; }
+
 static Tree build_sah() { Tree t; t.order.resize(T.size()); for (size_t i = 0; i < T.size(); ++i) t.order[i] = (int)i; t.n.reserve(2 * T.size()); t.root = sah_rec(t, 0, (int)T.size()); return t; }
 
 // PLOC over Morton-sorted leaves; leaf order is rebuilt by DFS afterwards
@@ -194,6 +230,9 @@ int main(int argc, char** argv)
     { Tree t = build_hybrid(64); eval("hyb64", t); }
     { Tree t = build_hybrid(256); eval("hyb256", t); }
     { Tree t = build_hybrid(4096); eval("hyb4096", t); }
+    { Tree t = build_hybrid2(256, 8); eval("lploc256", t); }
+    { Tree t = build_hybrid2(1024, 8); eval("lploc1024", t); }
+    { Tree t = build_hybrid2(256, 16); eval("lploc256r16", t); }
     { Tree t = build_ploc(8); eval("ploc r8", t); }
     { Tree t = build_ploc(25); eval("ploc r25", t); }
     { Tree t = build_sah(); eval("sah16", t); }

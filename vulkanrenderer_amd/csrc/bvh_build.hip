@@ -7,6 +7,8 @@
 //   bounds -> Morton codes (21 or 10 bits/axis) -> LSD radix sort (8-bit digits, LDS ranking)
 //   -> Karras 2012 hierarchy -> bottom-up AABB fit (atomic arrival flags).
 // Refit = re-transform the triangles in the stored Morton order + the same bottom-up fit.
+#include <stdio.h>
+
 #include "internal.hpp"
 
 namespace vkr {
@@ -368,6 +370,197 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint64_t* keys, int n, 
     if (i == 0) node_parent[0] = 0xffffffffu;
 }
 
+// ---------------------------------------------------------------- treelet rebuild (range-local PLOC) ------
+// The Karras tree splits by Morton bits, not by cost.  Every maximal subtree with <= TL_MAX triangles ("treelet") is
+// rebuilt here by locally-ordered agglomerative clustering (PLOC, Meister & Bittner 2018, run block-locally in LDS):
+// clusters start as the treelet's triangles in Morton order; each round every cluster picks the neighbour within TL_R
+// positions whose union box has the smallest area, mutual pairs merge, the cluster list is compacted in order.
+// Measured offline (tools/exp/bvh_quality_exp.cpp): -12 % node visits and -12 % triangle tests per AO ray.
+// The treelet keeps its triangle range [a, b], its root keeps its index (the parent's link stays valid) and the new
+// internal nodes reuse the range's own Karras indices ({a..b} minus the end the root does not sit on); triangles are
+// permuted inside the range into the DFS order of the new subtree, so every subtree still owns a contiguous range.
+// Runs between k_emit_sorted and k_fit: boxes and heights come from the fit, as before.
+constexpr int TL_MAX = 256;
+constexpr int TL_MIN = 4;
+constexpr int TL_R = 8;
+
+__global__ __launch_bounds__(256) void k_treelet_roots(const uint2* bin_range, const uint32_t* node_parent, int n_internal,
+                                                       uint32_t* list)   // [0] = count, [1] = work counter, [2..] = roots
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_internal) return;
+    const uint2 r = bin_range[i];
+    const uint32_t cnt = r.y - r.x + 1u;
+    if (cnt > (uint32_t)TL_MAX || cnt < (uint32_t)TL_MIN) return;
+    const uint32_t p = node_parent[i];
+    if (p != 0xffffffffu) {
+        const uint2 pr = bin_range[p];
+        if (pr.y - pr.x + 1u <= (uint32_t)TL_MAX) return;      // not maximal
+    }
+    list[2u + atomicAdd(&list[0], 1u)] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_treelet_ploc(uint32_t* list, int2* bin_child, uint2* bin_range, uint32_t* leaf_parent,
+                                                      uint32_t* node_parent, float4* tris, uint32_t* perm)
+{
+    __shared__ float s_lo[2][3][TL_MAX], s_hi[2][3][TL_MAX];
+    __shared__ short s_ref[2][TL_MAX];           // cluster -> node code: leaf t as -(t+1), created node k as k
+    __shared__ unsigned short s_cnt[2][TL_MAX];  // triangles in the cluster
+    __shared__ short s_nn[TL_MAX];
+    __shared__ short s_nodeL[TL_MAX], s_nodeR[TL_MAX], s_nodeParent[TL_MAX];
+    __shared__ unsigned short s_nodeCnt[TL_MAX], s_nodeLeft[TL_MAX];
+    __shared__ unsigned char s_nodeSide[TL_MAX], s_leafSide[TL_MAX];
+    __shared__ short s_leafParent[TL_MAX];
+    __shared__ unsigned short s_pos[TL_MAX];
+    __shared__ uint32_t s_wk[4], s_wc[4];
+    __shared__ uint32_t s_item;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    for (;;) {
+        if (t == 0) s_item = atomicAdd(&list[1], 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= list[0]) break;                              // uniform: every thread reads the same two values
+        const int r = (int)list[2u + item];
+        const uint2 rg = bin_range[r];
+        const int a = (int)rg.x, m = (int)(rg.y - rg.x) + 1;     // TL_MIN <= m <= TL_MAX
+        // ---- clusters = triangles in Morton order
+        float4 ta = make_float4(0, 0, 0, 0), tb = ta, tc = ta;
+        uint32_t my_perm = 0;
+        if (t < m) {
+            const float4* tp = tris + (size_t)(a + t) * 3;
+            ta = tp[0]; tb = tp[1]; tc = tp[2];
+            my_perm = perm[a + t];
+            const float v0[3] = {ta.x, ta.y, ta.z}, v1[3] = {ta.x + tb.x, ta.y + tb.y, ta.z + tb.z}, v2[3] = {ta.x + tc.x, ta.y + tc.y, ta.z + tc.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s_lo[0][k][t] = __builtin_fminf(v0[k], __builtin_fminf(v1[k], v2[k]));
+                s_hi[0][k][t] = __builtin_fmaxf(v0[k], __builtin_fmaxf(v1[k], v2[k]));
+            }
+            s_ref[0][t] = (short)(-(t + 1));
+            s_cnt[0][t] = 1;
+        }
+        __syncthreads();
+        int ncl = m, created = 0, cur = 0;
+        while (ncl > 1) {
+            // ---- nearest neighbour inside the window (smallest union area; ties: smallest index)
+            if (t < ncl) {
+                const float lx = s_lo[cur][0][t], ly = s_lo[cur][1][t], lz = s_lo[cur][2][t];
+                const float hx = s_hi[cur][0][t], hy = s_hi[cur][1][t], hz = s_hi[cur][2][t];
+                float best = 3.0e38f;
+                int bj = -1;
+                const int j0 = t - TL_R < 0 ? 0 : t - TL_R, j1 = t + TL_R > ncl - 1 ? ncl - 1 : t + TL_R;
+                for (int j = j0; j <= j1; ++j) {
+                    if (j == t) continue;
+                    const float dx = __builtin_fmaxf(hx, s_hi[cur][0][j]) - __builtin_fminf(lx, s_lo[cur][0][j]);
+                    const float dy = __builtin_fmaxf(hy, s_hi[cur][1][j]) - __builtin_fminf(ly, s_lo[cur][1][j]);
+                    const float dz = __builtin_fmaxf(hz, s_hi[cur][2][j]) - __builtin_fminf(lz, s_lo[cur][2][j]);
+                    const float area = dx * dy + dy * dz + dz * dx;
+                    if (area < best) { best = area; bj = j; }
+                }
+                s_nn[t] = (short)bj;
+            }
+            __syncthreads();
+            // ---- mutual pairs merge (the lower index creates the node), survivors are compacted in order
+            bool creator = false, keep = false;
+            int j = -1;
+            if (t < ncl) {
+                j = s_nn[t];
+                const bool mutual = (j >= 0) && ((int)s_nn[j] == t);
+                creator = mutual && t < j;
+                keep = !(mutual && t > j);
+            }
+            const unsigned long long mk = __ballot(keep), mc = __ballot(creator);
+            if (lane == 0) { s_wk[wave] = (uint32_t)__popcll(mk); s_wc[wave] = (uint32_t)__popcll(mc); }
+            __syncthreads();
+            uint32_t kbase = 0, cbase = 0, ktot = 0, ctot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) { kbase += s_wk[w]; cbase += s_wc[w]; }
+                ktot += s_wk[w]; ctot += s_wc[w];
+            }
+            const int nxt = cur ^ 1;
+            if (keep) {
+                const int pos = (int)(kbase + mbcnt64(mk));
+                if (creator) {
+                    const int k = created + (int)(cbase + mbcnt64(mc));
+                    const short rl = s_ref[cur][t], rr = s_ref[cur][j];
+                    s_nodeL[k] = rl; s_nodeR[k] = rr;
+                    s_nodeLeft[k] = s_cnt[cur][t];
+                    s_nodeCnt[k] = (unsigned short)(s_cnt[cur][t] + s_cnt[cur][j]);
+                    if (rl < 0) { s_leafParent[-rl - 1] = (short)k; s_leafSide[-rl - 1] = 0; }
+                    else { s_nodeParent[rl] = (short)k; s_nodeSide[rl] = 0; }
+                    if (rr < 0) { s_leafParent[-rr - 1] = (short)k; s_leafSide[-rr - 1] = 1; }
+                    else { s_nodeParent[rr] = (short)k; s_nodeSide[rr] = 1; }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        s_lo[nxt][c][pos] = __builtin_fminf(s_lo[cur][c][t], s_lo[cur][c][j]);
+                        s_hi[nxt][c][pos] = __builtin_fmaxf(s_hi[cur][c][t], s_hi[cur][c][j]);
+                    }
+                    s_ref[nxt][pos] = (short)k;
+                    s_cnt[nxt][pos] = s_nodeCnt[k];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { s_lo[nxt][c][pos] = s_lo[cur][c][t]; s_hi[nxt][c][pos] = s_hi[cur][c][t]; }
+                    s_ref[nxt][pos] = s_ref[cur][t];
+                    s_cnt[nxt][pos] = s_cnt[cur][t];
+                }
+            }
+            __syncthreads();
+            ncl = (int)ktot; created += (int)ctot; cur = nxt;
+            if (ctot == 0u) break;      // cannot happen (the globally closest pair is always mutual); guards the loop
+        }
+        const int root_local = m - 2;
+        const bool ok = (ncl == 1) && (created == m - 1);        // uniform
+        if (ok) {
+            if (t == 0) { s_nodeParent[root_local] = -1; s_nodeSide[root_local] = 0; }
+            __syncthreads();
+            // ---- DFS position of every leaf and first leaf of every node: left-sibling counts on the way to the root
+            if (t < m) {
+                uint32_t off = 0;
+                int p = s_leafParent[t], side = s_leafSide[t];
+                for (int guard = 0; guard < TL_MAX; ++guard) {
+                    if (side) off += s_nodeLeft[p];
+                    if (p == root_local) break;
+                    side = s_nodeSide[p];
+                    p = s_nodeParent[p];
+                }
+                s_pos[t] = (unsigned short)off;
+            }
+            __syncthreads();
+            // internal indices of the range: {a .. a+m-1} minus the end the root does not sit on; root keeps r
+            const int pa = a + 1;                                 // first non-root index, in both cases:
+            // r == a     : pool = a .. a+m-2, root = a      -> others a+1 .. a+m-2
+            // r == a+m-1 : pool = a+1 .. a+m-1, root = a+m-1 -> others a+1 .. a+m-2
+            auto gidx = [&](int k) { return k == root_local ? r : pa + k; };
+            auto code = [&](short ref) { return ref < 0 ? ~(a + (int)s_pos[-ref - 1]) : gidx(ref); };
+            if (t < m - 1) {
+                const int k = t;
+                uint32_t off = 0;
+                int c = k;
+                for (int guard = 0; guard < TL_MAX && c != root_local; ++guard) {
+                    const int p = s_nodeParent[c];
+                    if (s_nodeSide[c]) off += s_nodeLeft[p];
+                    c = p;
+                }
+                const int g = gidx(k);
+                bin_child[g] = make_int2(code(s_nodeL[k]), code(s_nodeR[k]));
+                bin_range[g] = make_uint2((uint32_t)a + off, (uint32_t)a + off + (uint32_t)s_nodeCnt[k] - 1u);
+                if (k != root_local) node_parent[g] = (uint32_t)gidx(s_nodeParent[k]);
+            }
+            if (t < m) {
+                const int np = a + (int)s_pos[t];
+                leaf_parent[np] = (uint32_t)gidx(s_leafParent[t]);
+                float4* tp = tris + (size_t)np * 3;              // every thread read its triangle before the first barrier
+                tp[0] = ta; tp[1] = tb; tp[2] = tc;
+                perm[np] = my_perm;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // padded AABB of sorted triangle j (padding keeps the slab test conservative w.r.t. the triangle test)
 VKR_DI float pad_abs_of(const BvhBounds* bnd)
 {
@@ -695,6 +888,61 @@ hipError_t instances_from_nodes_launch(vkr_ctx* c, const float model[16], hipStr
 
 #define VKR_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
+// Development check (VKR_VALIDATE_TREE=1): the binary tree is well formed before anything walks it -- every internal
+// node's children tile its range in order, leaves sit at their own position, parent links agree, node 0 is the root.
+static hipError_t validate_binary_tree(vkr_ctx* c, hipStream_t st)
+{
+    const uint32_t n = c->tri_count;
+    if (n < 2) return hipSuccess;
+    VKR_TRY(hipStreamSynchronize(st));
+    std::vector<int2> child(n - 1);
+    std::vector<uint2> range(n - 1);
+    std::vector<uint32_t> lpar(n), npar(n - 1), perm(n);
+    VKR_TRY(hipMemcpy(child.data(), c->d_bin_child.p, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost));
+    VKR_TRY(hipMemcpy(range.data(), c->d_bin_range.p, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost));
+    VKR_TRY(hipMemcpy(lpar.data(), c->d_leaf_parent.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    VKR_TRY(hipMemcpy(npar.data(), c->d_node_parent.p, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost));
+    VKR_TRY(hipMemcpy(perm.data(), c->d_perm.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    auto bad = [&](const char* what, uint32_t i) {
+        c->err = std::string("binary tree check failed: ") + what + " at node " + std::to_string(i);
+        fprintf(stderr, "[vkr] %s\n", c->err.c_str());
+        return hipErrorUnknown;
+    };
+    if (range[0].x != 0u || range[0].y != n - 1u || npar[0] != 0xffffffffu) return bad("root range/parent", 0);
+    std::vector<uint8_t> seen(n - 1, 0);
+    std::vector<uint32_t> stack{0u};
+    size_t visited = 0;
+    while (!stack.empty()) {
+        const uint32_t i = stack.back(); stack.pop_back();
+        if (i >= n - 1 || seen[i]) return bad("node index / revisit", i);
+        seen[i] = 1; ++visited;
+        const uint32_t lo = range[i].x, hi = range[i].y;
+        if (lo >= hi || hi >= n) return bad("range", i);
+        uint32_t at = lo;
+        const int ch[2] = {child[i].x, child[i].y};
+        for (int k = 0; k < 2; ++k) {
+            if (ch[k] < 0) {
+                const uint32_t leaf = (uint32_t)~ch[k];
+                if (leaf != at) return bad("leaf position", i);
+                if (lpar[leaf] != i) return bad("leaf parent", i);
+                at += 1;
+            } else {
+                const uint32_t j = (uint32_t)ch[k];
+                if (j >= n - 1) return bad("child index", i);
+                if (range[j].x != at || range[j].y > hi) return bad("child range", i);
+                if (npar[j] != i) return bad("node parent", i);
+                at = range[j].y + 1;
+                stack.push_back(j);
+            }
+        }
+        if (at != hi + 1) return bad("children do not tile the range", i);
+    }
+    if (visited != (size_t)n - 1) return bad("unreachable nodes", (uint32_t)visited);
+    std::vector<uint8_t> hit(n, 0);
+    for (uint32_t i = 0; i < n; ++i) { if (perm[i] >= n || hit[perm[i]]) return bad("perm is not a permutation", i); hit[perm[i]] = 1; }
+    return hipSuccess;
+}
+
 // Stage 1 of a build (everything up to the binary fit); the host reads back the binary height, then stage 2
 // collapses to wide nodes.  refit_only: stage 1 re-transforms + refits, stage 2 regathers wide boxes.
 hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
@@ -730,6 +978,15 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
                                                              c->d_bin_range.p, c->d_leaf_parent.p, c->d_node_parent.p);
     }
     k_emit_sorted<<<nb, 256, 0, st>>>(in, c->d_perm.p, c->d_tris.p);
+    if (!refit_only && n >= (uint32_t)TL_MIN && c->treelets) {
+        if (c->d_treelet.n < (size_t)n + 2) VKR_TRY(c->d_treelet.alloc((size_t)n + 2));
+        VKR_TRY(hipMemsetAsync(c->d_treelet.p, 0, 8, st));
+        k_treelet_roots<<<(n - 1 + 255u) / 256u, 256, 0, st>>>(c->d_bin_range.p, c->d_node_parent.p, (int)n - 1, c->d_treelet.p);
+        const uint32_t blocks = (uint32_t)(c->num_cus > 0 ? c->num_cus : 256) * 6u;
+        k_treelet_ploc<<<blocks, 256, 0, st>>>(c->d_treelet.p, c->d_bin_child.p, c->d_bin_range.p, c->d_leaf_parent.p,
+                                               c->d_node_parent.p, c->d_tris.p, c->d_perm.p);
+    }
+    if (!refit_only && c->validate_tree) VKR_TRY(validate_binary_tree(c, st));
     if (n == 1) {
         k_single<<<1, 64, 0, st>>>(c->d_tris.p, c->d_nodes.p, c->d_wide_bref.p, c->d_height.p, (WideCtl*)c->d_wide_ctl.p,
                                    c->d_bounds.p);

@@ -118,6 +118,8 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     c->W = desc->width;
     // experiment switches (development only; defaults are the shipped configuration)
     if (const char* e = getenv("VKR_MORTON_EMC")) c->morton_emc = (e[0] == '1');
+    if (const char* e = getenv("VKR_TREELETS")) c->treelets = (e[0] != '0');            // "0" = plain Karras tree
+    if (const char* e = getenv("VKR_VALIDATE_TREE")) c->validate_tree = (e[0] == '1');
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
     if (const char* e = getenv("VKR_SUN_MODE")) c->sun_packets = (e[0] != 'r');         // "ray" = one queue item per ray
     (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, c->device);
@@ -163,7 +165,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
     c->d_ib_infos.release(); c->d_ib_bounds.release(); c->d_ib_flags.release(); c->d_ib_tile.release();
     c->d_ib_counters.release(); c->d_ib_seg_begin.release(); c->d_ib_seg_rank.release(); c->d_ib_spans.release();
-    c->d_ib_order.release(); c->d_ibl_tables.release();
+    c->d_ib_order.release(); c->d_ibl_tables.release(); c->d_treelet.release();
     delete c;
 }
 
