@@ -20,6 +20,6 @@ for v in "$@"; do
 done
 cmd=""
 for n in "${names[@]}"; do
-  cmd+="echo == $n; VKR_LIB_PATH=\$PWD/vulkanrenderer_amd/lib/variants/libvkr_$n.so timeout -k 10 200 python -u bench.py --steps 10 --warmup 2 --cpu-seconds 0 ${BENCH_ARGS} 2>/dev/null | tail -1 | grep -oE '\"value\": [0-9.]+|\"trace_ms\": [0-9.]+|\"lane_util[a-z_]+\": [0-9.]+|\"nodes_per_ray\": [0-9.]+|\"tris_per_ray\": [0-9.]+|\"sun_shadow[a-z_]+\": [0-9.]+' | tr '\n' ' '; echo; "
+  cmd+="echo == $n; ${BENCH_ENV} VKR_LIB_PATH=\$PWD/vulkanrenderer_amd/lib/variants/libvkr_$n.so timeout -k 10 200 python -u bench.py --steps 10 --warmup 2 --cpu-seconds 0 ${BENCH_ARGS} 2>/dev/null | tail -1 | grep -oE '\"value\": [0-9.]+|\"trace_ms\": [0-9.]+|\"lane_util[a-z_]+\": [0-9.]+|\"nodes_per_ray\": [0-9.]+|\"tris_per_ray\": [0-9.]+|\"sun_shadow[a-z_]+\": [0-9.]+|\"lbvh_build_ms\": [0-9.]+|\"bvh_refit_ms\": [0-9.]+' | tr '\n' ' '; echo; "
 done
 /usr/local/graft/bin/gpurun --timeout 900 -- "$cmd" 2>&1 | grep -vE "^\[gpurun\] (sending|merged)"

@@ -380,9 +380,16 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint64_t* keys, int n, 
 // internal nodes reuse the range's own Karras indices ({a..b} minus the end the root does not sit on); triangles are
 // permuted inside the range into the DFS order of the new subtree, so every subtree still owns a contiguous range.
 // Runs between k_emit_sorted and k_fit: boxes and heights come from the fit, as before.
-constexpr int TL_MAX = 256;
+#ifndef VKR_TL_MAX
+#define VKR_TL_MAX 1024
+#endif
+#ifndef VKR_TL_R
+#define VKR_TL_R 8
+#endif
+constexpr int TL_MAX = VKR_TL_MAX;     // triangles per treelet = threads per block (64 .. 1024)
 constexpr int TL_MIN = 4;
-constexpr int TL_R = 8;
+constexpr int TL_R = VKR_TL_R;         // search window (positions either side)
+constexpr int TL_WAVES = TL_MAX / 64;
 
 __global__ __launch_bounds__(256) void k_treelet_roots(const uint2* bin_range, const uint32_t* node_parent, int n_internal,
                                                        uint32_t* list)   // [0] = count, [1] = work counter, [2..] = roots
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256) void k_treelet_roots(const uint2* bin_range, c
     list[2u + atomicAdd(&list[0], 1u)] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void k_treelet_ploc(uint32_t* list, int2* bin_child, uint2* bin_range, uint32_t* leaf_parent,
+__global__ __launch_bounds__(TL_MAX) void k_treelet_ploc(uint32_t* list, int2* bin_child, uint2* bin_range, uint32_t* leaf_parent,
                                                       uint32_t* node_parent, float4* tris, uint32_t* perm)
 {
     __shared__ float s_lo[2][3][TL_MAX], s_hi[2][3][TL_MAX];
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(256) void k_treelet_ploc(uint32_t* list, int2* bin_
     __shared__ unsigned char s_nodeSide[TL_MAX], s_leafSide[TL_MAX];
     __shared__ short s_leafParent[TL_MAX];
     __shared__ unsigned short s_pos[TL_MAX];
-    __shared__ uint32_t s_wk[4], s_wc[4];
+    __shared__ uint32_t s_wk[TL_WAVES], s_wc[TL_WAVES];
     __shared__ uint32_t s_item;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(256) void k_treelet_ploc(uint32_t* list, int2* bin_
             __syncthreads();
             uint32_t kbase = 0, cbase = 0, ktot = 0, ctot = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < TL_WAVES; ++w) {
                 if (w < wave) { kbase += s_wk[w]; cbase += s_wc[w]; }
                 ktot += s_wk[w]; ctot += s_wc[w];
             }
@@ -982,8 +989,8 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
         if (c->d_treelet.n < (size_t)n + 2) VKR_TRY(c->d_treelet.alloc((size_t)n + 2));
         VKR_TRY(hipMemsetAsync(c->d_treelet.p, 0, 8, st));
         k_treelet_roots<<<(n - 1 + 255u) / 256u, 256, 0, st>>>(c->d_bin_range.p, c->d_node_parent.p, (int)n - 1, c->d_treelet.p);
-        const uint32_t blocks = (uint32_t)(c->num_cus > 0 ? c->num_cus : 256) * 6u;
-        k_treelet_ploc<<<blocks, 256, 0, st>>>(c->d_treelet.p, c->d_bin_child.p, c->d_bin_range.p, c->d_leaf_parent.p,
+        const uint32_t blocks = (uint32_t)(c->num_cus > 0 ? c->num_cus : 256) * (TL_MAX <= 256 ? 6u : (TL_MAX <= 512 ? 3u : 2u));
+        k_treelet_ploc<<<blocks, TL_MAX, 0, st>>>(c->d_treelet.p, c->d_bin_child.p, c->d_bin_range.p, c->d_leaf_parent.p,
                                                c->d_node_parent.p, c->d_tris.p, c->d_perm.p);
     }
     if (!refit_only && c->validate_tree) VKR_TRY(validate_binary_tree(c, st));
