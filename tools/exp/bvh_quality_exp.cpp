@@ -132,6 +132,36 @@ static int hybrid2_rec(Tree& out, const Tree& lb, int n, int K, int radius)
 }
 static Tree build_hybrid2(int K, int radius) { Tree lb = build_lbvh(); Tree t; t.order = lb.order; t.n.reserve(3 * T.size()); t.root = hybrid2_rec(t, lb, lb.root, K, radius); return t; }
 
+// two-level: treelets (<= K, local PLOC) + the upper tree rebuilt by PLOC over the treelet roots in Morton order
+static void collect_cut(const Tree& lb, int n, int K, std::vector<int>& cut) { if (lb.n[n].count <= K) { cut.push_back(n); return; } collect_cut(lb, lb.n[n].l, K, cut); collect_cut(lb, lb.n[n].r, K, cut); }
+static Tree build_two_level(int K, int radius, int radius_top)
+{
+    Tree lb = build_lbvh(); Tree t; t.order = lb.order; t.n.reserve(3 * T.size());
+    std::vector<int> cut; collect_cut(lb, lb.root, K, cut);
+    std::vector<int> cl;
+    for (int c : cut) cl.push_back(ploc_range(t, lb.n[c].first, lb.n[c].first + lb.n[c].count, radius));
+    for (int id : cl) if (t.n[id].l < 0) { /* single leaf: ploc_range set first */ }
+    while (cl.size() > 1) { int m = (int)cl.size(); std::vector<int> nn(m);
+        for (int i = 0; i < m; ++i) { float best = 1e30f; int bj = -1;
+            for (int j = std::max(0, i - radius_top); j <= std::min(m - 1, i + radius_top); ++j) { if (j == i) continue; Box b = t.n[cl[i]].box; b.grow(t.n[cl[j]].box); float a = b.area(); if (a < best) { best = a; bj = j; } }
+            nn[i] = bj; }
+        std::vector<int> next;
+        for (int i = 0; i < m; ++i) { int j = nn[i];
+            if (nn[j] == i) { if (i < j) { int id = (int)t.n.size(); t.n.emplace_back(); t.n[id].l = cl[i]; t.n[id].r = cl[j]; t.n[id].box = t.n[cl[i]].box; t.n[id].box.grow(t.n[cl[j]].box); t.n[id].count = t.n[cl[i]].count + t.n[cl[j]].count; next.push_back(id); } }
+            else next.push_back(cl[i]); }
+        cl.swap(next); }
+    t.root = cl[0];
+    // global DFS re-order (ranges of whole treelets move)
+    std::vector<int> old = t.order, neworder; neworder.reserve(old.size());
+    std::vector<std::pair<int, int>> st{{t.root, 0}};
+    while (!st.empty()) { auto [n, ph] = st.back(); st.pop_back();
+        if (t.n[n].l < 0) { int tri = old[t.n[n].first]; t.n[n].first = (int)neworder.size(); neworder.push_back(tri); continue; }
+        if (ph == 0) { st.push_back({n, 1}); st.push_back({t.n[n].r, 0}); st.push_back({t.n[n].l, 0}); }
+        else t.n[n].first = t.n[t.n[n].l].first; }
+    t.order = neworder;
+    return t;
+}
+
 static Tree build_sah() { Tree t; t.order.resize(T.size()); for (size_t i = 0; i < T.size(); ++i) t.order[i] = (int)i; t.n.reserve(2 * T.size()); t.root = sah_rec(t, 0, (int)T.size()); return t; }
 
 // PLOC over Morton-sorted leaves; leaf order is rebuilt by DFS afterwards
@@ -233,6 +263,8 @@ int main(int argc, char** argv)
     { Tree t = build_hybrid2(256, 8); eval("lploc256", t); }
     { Tree t = build_hybrid2(1024, 8); eval("lploc1024", t); }
     { Tree t = build_hybrid2(256, 16); eval("lploc256r16", t); }
+    { Tree t = build_two_level(1024, 8, 8); eval("2lvl r8", t); }
+    { Tree t = build_two_level(1024, 8, 25); eval("2lvl r25", t); }
     { Tree t = build_ploc(8); eval("ploc r8", t); }
     { Tree t = build_ploc(25); eval("ploc r25", t); }
     { Tree t = build_sah(); eval("sah16", t); }
