@@ -259,7 +259,10 @@ int main(int argc, char** argv)
     { Tree t = build_hybrid(16); eval("hyb16", t); }
     { Tree t = build_hybrid(64); eval("hyb64", t); }
     { Tree t = build_hybrid(256); eval("hyb256", t); }
+    { Tree t = build_hybrid(1024); eval("hyb1024", t); }
+    { Tree t = build_hybrid(2048); eval("hyb2048", t); }
     { Tree t = build_hybrid(4096); eval("hyb4096", t); }
+    { Tree t = build_hybrid(32768); eval("hyb32768", t); }
     { Tree t = build_hybrid2(256, 8); eval("lploc256", t); }
     { Tree t = build_hybrid2(1024, 8); eval("lploc1024", t); }
     { Tree t = build_hybrid2(256, 16); eval("lploc256r16", t); }
