@@ -121,6 +121,50 @@ def test_bvh_structure_after_build_and_refit(torch_mod):
     ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["tiny", "duplicates", "coplanar_grid", "street", "treelets_off"])
+def test_treelet_rebuild_keeps_the_tree_well_formed(torch_mod, oracle_mod, kind, monkeypatch):
+    """k_treelet_ploc under VKR_VALIDATE_TREE=1 (host-side check of the binary tree before the fit walks it) on the
+    inputs that stress it: fewer triangles than a treelet, hundreds of identical triangles (every union area ties),
+    a regular coplanar grid (ties between different pairs), a normal scene; then the wide tree's structure and one
+    traced frame against the oracle.  VKR_TREELETS=0 (plain Karras tree) must give the same pixels."""
+    from vulkanrenderer_amd import FrameState, make_street_scene
+    from vulkanrenderer_amd.renderer import PassExecuteContext, RtaoComputePass
+    from vulkanrenderer_amd.scenes import Material, Mesh, SceneData, grid_mesh, trs, VERTEX_FLOATS
+    monkeypatch.setenv("VKR_VALIDATE_TREE", "1")
+    if kind == "treelets_off":
+        monkeypatch.setenv("VKR_TREELETS", "0")
+    if kind == "tiny":
+        scene = SceneData([grid_mesh(1, 2, 0)], [Material()], np.zeros(2, dtype=np.uint32),
+                          np.stack([trs((0, 0, 3), (4, 1, 4)), trs((0.5, 0.7, 3.5), (1, 1, 1))]).astype(np.float32), "tiny")   # 8 triangles
+    elif kind == "duplicates":
+        g = grid_mesh(1, 1, 0)
+        xf = np.stack([trs((0, 0, 3), (4, 1, 4))] * 150 + [trs((0.5, 0.6, 3.5), (1, 1, 1))] * 3).astype(np.float32)
+        scene = SceneData([g], [Material()], np.zeros(len(xf), dtype=np.uint32), xf, "dups")                                  # 306 triangles
+    elif kind == "coplanar_grid":
+        scene = SceneData([grid_mesh(40, 40, 0)], [Material()], np.zeros(2, dtype=np.uint32),
+                          np.stack([trs((-4, 0, 1), (8, 1, 8)), trs((-1, 0.8, 3), (2, 1, 2))]).astype(np.float32), "grid")     # 6400 triangles
+    else:
+        scene = make_street_scene(5, 0.02, "bvh")
+    scene.cameras = scene.cameras or [((0.3, 2.5, -1.0), (0.2, 0.0, 4.0))]
+    W, H = 64, 40
+    ctx, rt, gb = _ctx(scene, W, H)
+    info = rt.info()
+    assert info.triangle_count == scene.triangle_count()
+    nodes, tris = rt.download()
+    _check_bvh_structure(nodes, tris, scene, info)
+    osc = oracle_mod.OracleScene(scene)
+    rp = RtaoComputePass(ctx, gb, atrous_iterations=2)
+    op = oracle_mod.OracleRtaoPass(osc, W, H, 2)
+    ubo = FrameState(W, H, ray_count=4).update(*scene.cameras[0])
+    depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+    assert (valid > 0).mean() > 0.05
+    gb.upload(depth, normal, wp, ng, valid)
+    rp.execute(PassExecuteContext(ubo=ubo))
+    ctx.sync()
+    assert to_np_u16(rp.rtao_full).tobytes() == op.execute(ubo, depth, normal).tobytes()
+    ctx.close()
+
+
 def test_refit_matches_oracle_and_rebuild(torch_mod, oracle_mod):
     """updateTopLevelAS (RayTracingContext.cpp:163-197): traced results after a refit equal the oracle's on the moved
     instances and equal a from-scratch build's (results do not depend on the tree)."""

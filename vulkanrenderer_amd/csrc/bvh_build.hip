@@ -464,7 +464,15 @@ __global__ __launch_bounds__(TL_MAX) void k_treelet_ploc(uint32_t* list, int2* b
                     const float dy = __builtin_fmaxf(hy, s_hi[cur][1][j]) - __builtin_fminf(ly, s_lo[cur][1][j]);
                     const float dz = __builtin_fmaxf(hz, s_hi[cur][2][j]) - __builtin_fminf(lz, s_lo[cur][2][j]);
                     const float area = dx * dy + dy * dz + dz * dx;
-                    if (area < best) { best = area; bj = j; }
+                    // ties (coincident or regularly spaced geometry): the closer position wins, then the pair partner
+                    // t^1, then the smaller index -- identical boxes pair up (0,1)(2,3).. and the subtree stays
+                    // balanced instead of degenerating into a chain
+                    bool better = area < best;
+                    if (area == best && bj >= 0) {
+                        const int dj = j > t ? j - t : t - j, db = bj > t ? bj - t : t - bj;
+                        better = dj < db || (dj == db && j == (t ^ 1));
+                    }
+                    if (better) { best = area; bj = j; }
                 }
                 s_nn[t] = (short)bj;
             }

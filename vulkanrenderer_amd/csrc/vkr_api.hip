@@ -369,15 +369,22 @@ int vkr_bvh_build(vkr_ctx* c, void* stream)
         c->has_bvh = true;
         return VKR_OK;
     }
-    // 21 bits/axis; if the wide tree comes out deeper than the traversal stack allows (pathological duplicate
-    // centroids), fall back to 10 bits/axis where the index tie-break bounds the height by 30 + log2(n).
-    const uint32_t tries[2] = {21u, 10u};
-    for (int t = 0; t < 2; ++t) {
+    // 21 bits/axis with the treelet rebuild; if the wide tree comes out deeper than the traversal stack allows, first
+    // drop the treelets (clustering has no depth bound), then fall back to 10 bits/axis, where the index tie-break of
+    // the Karras tree bounds the height by 30 + log2(n) (pathological duplicate centroids).
+    const uint32_t tries[3] = {21u, 21u, 10u};
+    const bool want_treelets = c->treelets;
+    for (int t = 0; t < 3; ++t) {
+        if (t == 1 && !want_treelets) continue;                  // same configuration as try 0
         c->morton_bits = tries[t];
-        HIP_OR_FAIL(c, bvh_build_launch(c, false, st));
+        c->treelets = want_treelets && t == 0;
+        hipError_t be = bvh_build_launch(c, false, st);
+        if (be != hipSuccess) { c->treelets = want_treelets; HIP_OR_FAIL(c, be); }
         // the binary height bounds the number of BFS levels of the collapse; it is one word
-        if (int rc = read_height_and_bounds(c, st)) return rc;
-        HIP_OR_FAIL(c, bvh_wide_launch(c, c->bvh_height, st));
+        if (int rc = read_height_and_bounds(c, st)) { c->treelets = want_treelets; return rc; }
+        hipError_t we = bvh_wide_launch(c, c->bvh_height, st);
+        c->treelets = want_treelets;
+        HIP_OR_FAIL(c, we);
         uint32_t ctl[4] = {0, 0, 0, 0};
         HIP_OR_FAIL(c, hipMemcpyAsync(ctl, c->d_wide_ctl.p, 16, hipMemcpyDeviceToHost, st));
         HIP_OR_FAIL(c, hipStreamSynchronize(st));
