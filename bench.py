@@ -322,6 +322,14 @@ def main():
     gathered = torch.zeros((n, 2, hb, W), dtype=torch.int16, device=dev)
     sun16 = torch.zeros((H, W), dtype=torch.float16, device=dev)
 
+    pending = []   # the [rtao_full | sun] gather of the previous frame, still in flight on the communicator's stream
+
+    def finish_output_gather():
+        if pending:
+            work, planes = pending.pop()
+            work.wait()
+            bands.unpack_frame(gathered, planes, H, n)
+
     def step(i):
         rpass.gbuffer = gbs[i]
         if n == 1:
@@ -330,10 +338,11 @@ def main():
                 shadows.gb = gbs[i]
                 shadows.sun(ubos[i])
             return
-        rpass.traceStripes(ubos[i], rank, n)
+        rpass.traceStripes(ubos[i], rank, n)                                  # overlaps the previous frame's output gather
         hc = rpass.historyCurr()
         plan.pack(hc, rank, hist_send)
         work = bands.all_gather_bytes(hist_send, hist_recv, async_op=True)     # overlaps the sun-shadow kernel below
+        finish_output_gather()                                                 # frame i-1 is assembled before its planes are rewritten
         planes = [rpass.rtao_full]
         if shadows is not None:
             shadows.gb = gbs[i]
@@ -344,12 +353,12 @@ def main():
         plan.unpack(hist_recv, hc)
         rpass.denoiseBand(ubos[i], y0, y1)
         bands.pack_band(planes, H, n, rank, packed)
-        bands.all_gather_frame(packed, gathered)
-        bands.unpack_frame(gathered, planes, H, n)
+        pending.append((bands.all_gather_frame(packed, gathered, async_op=True), planes))
 
     for i in range(Wu):
         step(i)
         log(f"warmup step {i} issued")
+    finish_output_gather()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -357,6 +366,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(Wu, Wu + K):
         step(i)
+    finish_output_gather()                 # the last frame is assembled inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -42,20 +42,11 @@ def pack_band(planes: Sequence[torch.Tensor], H: int, n: int, r: int, out: torch
     return out
 
 
-def all_gather_frame(packed: torch.Tensor, gathered: torch.Tensor, group=None) -> torch.Tensor:
-    """packed (PLANES, Hb, W) from every rank -> gathered (n, PLANES, Hb, W).  One collective per frame.
-    The payload travels as raw bytes: neither RCCL nor gloo has a 16-bit integer type, and no reduction is done."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if packed.is_cuda and dist.get_backend(group) == "gloo":
-            # gloo has no device-side path worth using: stage through the host (CPU rehearsals of the GPU schedule)
-            h_out = torch.empty(gathered.shape, dtype=gathered.dtype)
-            dist.all_gather_into_tensor(h_out.view(-1).view(torch.uint8), packed.cpu().view(-1).view(torch.uint8), group=group)
-            gathered.copy_(h_out)
-            return gathered
-        dist.all_gather_into_tensor(gathered.view(-1).view(torch.uint8), packed.view(-1).view(torch.uint8), group=group)
-    else:
-        gathered.view(-1)[: packed.numel()].copy_(packed.view(-1))
-    return gathered
+def all_gather_frame(packed: torch.Tensor, gathered: torch.Tensor, group=None, async_op: bool = False):
+    """packed (PLANES, Hb, W) from every rank -> gathered (n, PLANES, Hb, W).  One collective.
+    The payload travels as raw bytes: neither RCCL nor gloo has a 16-bit integer type, and no reduction is done.
+    Returns a handle whose wait() orders the current stream after the collective (see all_gather_bytes)."""
+    return all_gather_bytes(packed, gathered, group=group, async_op=async_op)
 
 
 def unpack_frame(gathered: torch.Tensor, planes: Sequence[torch.Tensor], H: int, n: int) -> None:
