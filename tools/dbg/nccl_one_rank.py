@@ -14,6 +14,19 @@ assert torch.equal(recv[0], send)
 recv.zero_()
 dist.all_gather_into_tensor(recv.view(-1).view(torch.uint8), send.view(-1).view(torch.uint8))
 assert torch.equal(recv[0], send)
+# two collectives in flight, waited out of issue order around independent kernels (bench.py's frame pipeline)
+from vulkanrenderer_amd import bands
+a_send = torch.randint(-30000, 30000, (2, 270, 3840), dtype=torch.int16, device="cuda"); a_recv = torch.zeros((1, 2, 270, 3840), dtype=torch.int16, device="cuda")
+b_send = torch.randint(-30000, 30000, (272, 3840), dtype=torch.int16, device="cuda"); b_recv = torch.zeros((1, 272, 3840), dtype=torch.int16, device="cuda")
+for it in range(3):
+    wa = bands.all_gather_frame(a_send, a_recv, async_op=True)
+    y = (send.float() * 2).sum()
+    wb = bands.all_gather_bytes(b_send, b_recv, async_op=True)
+    wa.wait(); z = a_recv.float().sum()
+    wb.wait()
+    assert torch.equal(b_recv[0], b_send) and torch.equal(a_recv[0], a_send)
+    a_send += 1; b_send -= 1
+torch.cuda.synchronize()
 dist.barrier()
 t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
 print("rccl one-rank ok", float(x), float(t))
