@@ -280,6 +280,18 @@ VKR_API int vkr_gbuffer_primary(vkr_ctx* ctx, const float ubo[VKR_UBO_FLOATS], u
                                 uint16_t* normal_rgba16f, float* world_pos, float* geom_normal, uint8_t* valid,
                                 void* stream);
 
+/* The same with the prepass's MSAA (DepthPrepass.cpp:31-65: both attachments are multisampled and resolve with
+ * VK_RESOLVE_MODE_AVERAGE; no sample shading, DepthPrepassPipeline.cpp:96).  The reference takes the device's maximum
+ * sample count, the driver's sample positions and its resolve arithmetic; this entry point fixes one definition:
+ * `samples` in {1, 2, 4, 8} at the Vulkan standard sample locations; coverage and depth test per sample; the fragment
+ * outputs of the winning primitive evaluated once at the pixel centre (extrapolated on its plane when the centre is not
+ * covered) -- the MASK discard too; fp16 per sample; resolve = float32 mean in sample order, rounded to fp16; uncovered
+ * samples hold the clear values (0 and (0.5,0.5,1,1)).  valid = resolved depth > 1e-6.  world_pos / geom_normal keep the
+ * pixel-centre semantics of vkr_gbuffer_primary.  samples = 1 is vkr_gbuffer_primary. */
+VKR_API int vkr_gbuffer_primary_msaa(vkr_ctx* ctx, const float ubo[VKR_UBO_FLOATS], uint32_t samples,
+                                     uint16_t* linear_depth_r16f, uint16_t* normal_rgba16f, float* world_pos,
+                                     float* geom_normal, uint8_t* valid, void* stream);
+
 /* ---------------------------------------------------------------- GPU-driven indirect build */
 
 /* SURVEY 8(f) row 4 (BASELINE configs[2]).  Replaces the per-frame CPU loop FrameManager::prepareSharedOpaqueIndirect

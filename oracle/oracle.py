@@ -166,14 +166,19 @@ class OracleScene:
         return {"rays": int(out[0]), "nodes": int(out[1]), "tris": int(out[2])}
 
     # ---- passes -----------------------------------------------------------------------------------
-    def gbuffer(self, ubo, W, H):
+    def gbuffer(self, ubo, W, H, samples=1):
         depth = np.zeros((H, W), dtype=np.uint16)
         normal = np.zeros((H, W, 4), dtype=np.uint16)
         wp = np.zeros((H, W, 3), dtype=np.float32)
         ng = np.zeros((H, W, 3), dtype=np.float32)
         valid = np.zeros((H, W), dtype=np.uint8)
         u = _f32(ubo)
-        self.L.orc_gbuffer(self.handle, _p(u), W, H, _p(depth), _p(normal), _p(wp), _p(ng), _p(valid))
+        if samples == 1:
+            self.L.orc_gbuffer(self.handle, _p(u), W, H, _p(depth), _p(normal), _p(wp), _p(ng), _p(valid))
+        else:
+            self.L.orc_gbuffer_msaa.restype = None
+            self.L.orc_gbuffer_msaa.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+            self.L.orc_gbuffer_msaa(self.handle, _p(u), W, H, int(samples), _p(depth), _p(normal), _p(wp), _p(ng), _p(valid))
         return depth, normal, wp, ng, valid
 
     def trace(self, ubo, depth, hist_prev, y0=0, y1=None, want_mask=False):

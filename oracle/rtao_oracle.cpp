@@ -386,7 +386,10 @@ static inline bool tri_test(const Tri& tr, V3 o, V3 d, float tmin, float tbest, 
     return true;
 }
 
-static bool query(Scene& s, V3 o, V3 d, float tmin, float tmax, QueryMode mode, bool tie, Hit* hit)
+// centre_dir (MSAA prepass only): the fragment shader runs once per pixel per primitive, so the MASK discard of a
+// candidate is decided with the barycentrics of the PIXEL-CENTRE ray on the triangle's plane (extrapolated when the
+// centre is not covered), not with those of the sample ray.
+static bool query(Scene& s, V3 o, V3 d, float tmin, float tmax, QueryMode mode, bool tie, Hit* hit, const V3* centre_dir = nullptr)
 {
     uint64_t c_nodes = 0, c_tris = 0;
     float tbest = tmax;
@@ -398,7 +401,19 @@ static bool query(Scene& s, V3 o, V3 d, float tmin, float tmax, QueryMode mode, 
         float t, u, v;
         ++c_tris;
         if (!tri_test(tr, o, d, tmin, tbest, best_flat, tie, &t, &u, &v)) return false;
-        if (mode == Q_AO && !ao_confirm(s, tr, u, v)) return false;
+        if (mode == Q_AO) {
+            float cu = u, cv = v;
+            if (centre_dir && !tr.opaque) {
+                V3 pc = cross3(*centre_dir, tr.e2);
+                float detc = dot3(tr.e1, pc);
+                if (detc == 0.0f) return false;            // plane edge-on to the centre ray: no fragment value exists
+                float invc = 1.0f / detc;
+                V3 tvec = o - tr.v0;
+                cu = dot3(tvec, pc) * invc;
+                cv = dot3(*centre_dir, cross3(tvec, tr.e1)) * invc;
+            }
+            if (!ao_confirm(s, tr, cu, cv)) return false;
+        }
         tbest = t; best_flat = tr.flat; best_tri = ti; bu = u; bv = v; found = true;
         return mode == Q_SHADOW;  // any-hit terminates
     };
@@ -1123,6 +1138,111 @@ void orc_gbuffer(void* sp, const float* ubo, int W, int H, uint16_t* depth, uint
             if (worldPosOut) { worldPosOut[3 * o] = wp.x; worldPosOut[3 * o + 1] = wp.y; worldPosOut[3 * o + 2] = wp.z; }
             if (ngOut) { ngOut[3 * o] = ng.x; ngOut[3 * o + 1] = ng.y; ngOut[3 * o + 2] = ng.z; }
             if (validOut) validOut[o] = valid ? 1 : 0;
+        }
+}
+
+// DepthPrepass with MSAA (DepthPrepass.cpp:31-65: both colour attachments resolve with eAverage; the pipeline has no
+// sample shading, DepthPrepassPipeline.cpp:96).  The reference takes the device's maximum sample count, the driver's
+// sample positions and its resolve arithmetic; this restatement fixes: `samples` in {1,2,4,8} at the Vulkan standard
+// sample locations; coverage and depth test per sample (a ray through the sample position, closest non-discarded
+// primitive); the fragment's outputs evaluated ONCE per primitive at the pixel centre (attributes extrapolated on the
+// triangle's plane when the centre is not covered); each sample stores them as fp16; the resolve is the float32 mean
+// in sample order, rounded to fp16.  Uncovered samples hold the clear values (depth 0, normal (0.5,0.5,1,1)).
+// world position / Ng / valid keep the pixel-centre semantics of orc_gbuffer (they stand for pbr.frag's varyings).
+static const float kSamplePos[4][8][2] = {
+    {{0.5f, 0.5f}},
+    {{0.75f, 0.75f}, {0.25f, 0.25f}},
+    {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.125f, 0.625f}, {0.625f, 0.875f}},
+    {{0.5625f, 0.3125f}, {0.4375f, 0.6875f}, {0.8125f, 0.5625f}, {0.3125f, 0.1875f},
+     {0.1875f, 0.8125f}, {0.0625f, 0.4375f}, {0.6875f, 0.9375f}, {0.9375f, 0.0625f}}};
+
+static V3 primary_dir(const float* invProj, const float* invView, float fx, float fy, int W, int H)
+{
+    float u = fx / (float)W, v = fy / (float)H;
+    float fv[4];
+    mul_m4_v4(invProj, u * 2.0f - 1.0f, v * 2.0f - 1.0f, 1.0f, 1.0f, fv);
+    V3 dv = normalize3(V3{fv[0] / fv[3], fv[1] / fv[3], fv[2] / fv[3]});
+    return normalize3(mul_m3_v3(invView, dv));
+}
+
+// the fragment outputs of triangle `ti` for the pixel whose centre ray is (cam, dc): linear view Z and encoded normal
+static void fragment_outputs(const Scene& s, const float* view, V3 cam, V3 dc, uint32_t ti, float t_s, float u_s, float v_s,
+                             V3 d_s, float* z_out, V3* n_out)
+{
+    const Tri& tr = s.tris[ti];
+    float t = t_s, u = u_s, v = v_s;
+    V3 dir = d_s;
+    V3 pc = cross3(dc, tr.e2);
+    float detc = dot3(tr.e1, pc);
+    if (detc != 0.0f) {                                   // centre ray on the triangle's plane (else: the sample's own hit)
+        float invc = 1.0f / detc;
+        V3 tvec = cam - tr.v0;
+        V3 qvec = cross3(tvec, tr.e1);
+        u = dot3(tvec, pc) * invc;
+        v = dot3(dc, qvec) * invc;
+        t = dot3(tr.e2, qvec) * invc;
+        dir = dc;
+    }
+    V3 wp = cam + dir * t;
+    float vp[4];
+    mul_m4_v4(view, wp.x, wp.y, wp.z, 1.0f, vp);
+    *z_out = -vp[2];
+    V3 n = normalize3(cross3(tr.e1, tr.e2));
+    if (s.mesh_has_normals[tr.mesh]) {
+        float N[9];
+        normal_matrix(&s.inst_xf[12 * (size_t)tr.inst], N);
+        const uint32_t ioff = s.lut_index_offset[tr.mesh] + 3 * tr.prim;
+        V3 vn[3];
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t gi = s.indices[ioff + k];
+            vn[k] = world_normal(N, V3{s.normals[3 * gi], s.normals[3 * gi + 1], s.normals[3 * gi + 2]});
+        }
+        const float w0 = (1.0f - u) - v;
+        n = normalize3(V3{(vn[0].x * w0 + vn[1].x * u) + vn[2].x * v, (vn[0].y * w0 + vn[1].y * u) + vn[2].y * v,
+                          (vn[0].z * w0 + vn[1].z * u) + vn[2].z * v});
+    }
+    *n_out = n;
+}
+
+void orc_gbuffer_msaa(void* sp, const float* ubo, int W, int H, int samples, uint16_t* depth, uint16_t* normal,
+                      float* worldPosOut, float* ngOut, uint8_t* validOut)
+{
+    Scene& s = *(Scene*)sp;
+    const int set = samples == 8 ? 3 : (samples == 4 ? 2 : (samples == 2 ? 1 : 0));
+    const int S = 1 << set;
+    float invProj[16], invView[16];
+    inverse_m4(ubo + 32, invProj);
+    inverse_m4(ubo + 16, invView);
+    V3 cam = V3{ubo[84], ubo[85], ubo[86]};
+    // centre-semantics outputs first (and the S == 1 images)
+    orc_gbuffer(sp, ubo, W, H, S == 1 ? depth : nullptr, S == 1 ? normal : nullptr, worldPosOut, ngOut, S == 1 ? validOut : nullptr);
+    if (S == 1) return;
+    const float invS = 1.0f / (float)S;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t o = (size_t)y * W + x;
+            V3 dc = primary_dir(invProj, invView, (float)x + 0.5f, (float)y + 0.5f, W, H);
+            float zsum = 0.0f, nsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < S; ++k) {
+                V3 ds = primary_dir(invProj, invView, (float)x + kSamplePos[set][k][0], (float)y + kSamplePos[set][k][1], W, H);
+                Hit h;
+                uint16_t zh = 0, nh[4] = {float_to_half(0.5f), float_to_half(0.5f), float_to_half(1.0f), float_to_half(1.0f)};
+                if (query(s, cam, ds, 0.0f, 1.0e30f, Q_AO, true, &h, &dc)) {
+                    float z;
+                    V3 n;
+                    fragment_outputs(s, ubo + 16, cam, dc, h.tri, h.t, h.u, h.v, ds, &z, &n);
+                    zh = float_to_half(z);
+                    nh[0] = float_to_half(n.x * 0.5f + 0.5f); nh[1] = float_to_half(n.y * 0.5f + 0.5f);
+                    nh[2] = float_to_half(n.z * 0.5f + 0.5f); nh[3] = float_to_half(1.0f);
+                }
+                zsum = zsum + half_to_float(zh);
+                for (int c = 0; c < 4; ++c) nsum[c] = nsum[c] + half_to_float(nh[c]);
+            }
+            uint16_t zr = float_to_half(zsum * invS);
+            if (depth) depth[o] = zr;
+            if (normal) for (int c = 0; c < 4; ++c) normal[o * 4 + c] = float_to_half(nsum[c] * invS);
+            if (validOut) validOut[o] = half_to_float(zr) > 1e-6f ? 1 : 0;
         }
 }
 

@@ -115,6 +115,7 @@ SYMBOLS = {
     "vkr_shadow_sun": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), C.c_float, C.c_float, _P, _P]),
     "vkr_shadow_point": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), _P, _P]),
     "vkr_gbuffer_primary": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P]),
+    "vkr_gbuffer_primary_msaa": (C.c_int, [_P, C.POINTER(C.c_float), C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "vkr_indirect_upload": (C.c_int, [_P, C.POINTER(IndirectDesc)]),
     "vkr_indirect_slots_download": (C.c_int, [_P, _P]),
     "vkr_indirect_prepare": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, _P, C.c_uint32, _P]),

@@ -205,5 +205,7 @@ hipError_t shadow_point_launch(vkr_ctx* c, const float* wp, const float* ng, con
                                const float P[3], float* out, hipStream_t st);
 hipError_t gbuffer_launch(vkr_ctx* c, const FrameParams& fp, uint16_t* depth, uint16_t* normal, float* wp, float* ng,
                           uint8_t* valid, hipStream_t st);
+hipError_t gbuffer_msaa_launch(vkr_ctx* c, const FrameParams& fp, int samples, uint16_t* depth, uint16_t* normal, float* wp,
+                               float* ng, uint8_t* valid, hipStream_t st);
 
 }  // namespace vkr

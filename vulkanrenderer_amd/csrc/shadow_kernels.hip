@@ -175,6 +175,106 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer(SceneDev sc, FrameP
 }
 
 
+// DepthPrepass with MSAA (DepthPrepass.cpp:31-65, both attachments resolve with eAverage; no sample shading,
+// DepthPrepassPipeline.cpp:96): per sample a ray through the Vulkan standard sample position picks the closest
+// non-discarded primitive; that primitive's fragment outputs are evaluated once, at the pixel centre (extrapolated on
+// the triangle's plane when the centre is not covered), stored as fp16 per sample, averaged in float32 in sample order.
+// Definition and rationale: oracle/rtao_oracle.cpp orc_gbuffer_msaa.  Only depth / normal / valid are written here; the
+// pixel-centre outputs (world position, Ng) come from k_gbuffer.
+__constant__ float c_sample_pos[4][8][2] = {
+    {{0.5f, 0.5f}},
+    {{0.75f, 0.75f}, {0.25f, 0.25f}},
+    {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.125f, 0.625f}, {0.625f, 0.875f}},
+    {{0.5625f, 0.3125f}, {0.4375f, 0.6875f}, {0.8125f, 0.5625f}, {0.3125f, 0.1875f},
+     {0.1875f, 0.8125f}, {0.0625f, 0.4375f}, {0.6875f, 0.9375f}, {0.9375f, 0.0625f}}};
+
+VKR_DI V3 primary_dir(const FrameParams& fp, float fx, float fy)
+{
+    const float u = fx / (float)fp.W, v = fy / (float)fp.H;
+    float fv[4];
+    mul_m4_v4(fp.invProj, u * 2.0f - 1.0f, v * 2.0f - 1.0f, 1.0f, 1.0f, fv);
+    const V3 dv = normalize3(V3{fv[0] / fv[3], fv[1] / fv[3], fv[2] / fv[3]});
+    return normalize3(mul_m3_v3(fp.invView, dv));
+}
+
+__global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer_msaa(SceneDev sc, FrameParams fp, int set, uint16_t* depth,
+                                                                  uint16_t* normal, uint8_t* validOut, uint32_t tiles_x)
+{
+    __shared__ uint32_t s_stack[2 * VKR_LDS_STACK * VKR_TRACE_BLOCK];
+    uint32_t* stack = s_stack + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = (int)(blockIdx.x % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = (int)(blockIdx.x / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (x >= fp.W || y >= fp.H) return;
+    const size_t o = (size_t)y * fp.W + x;
+    const int S = 1 << set;
+    const V3 cam = V3{fp.camPos[0], fp.camPos[1], fp.camPos[2]};
+    const V3 dc = primary_dir(fp, (float)x + 0.5f, (float)y + 0.5f);
+    float zsum = 0.0f, n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    for (int k = 0; k < S; ++k) {
+        const V3 ds = primary_dir(fp, (float)x + c_sample_pos[set][k][0], (float)y + c_sample_pos[set][k][1]);
+        HitDev h;
+        uint16_t zh = 0, e0 = float_to_half(0.5f), e1h = float_to_half(0.5f), e2h = float_to_half(1.0f), e3 = float_to_half(1.0f);
+        if (traverse<Q_PRIMARY_MS, false>(sc, cam, ds, 0.0f, 1.0e30f, &h, stack, nullptr, dc)) {
+            const float4* tp = sc.tris + (size_t)h.tri * 3;
+            const float4 a = tp[0], b = tp[1], c = tp[2];
+            const V3 v0 = V3{a.x, a.y, a.z}, e1 = V3{b.x, b.y, b.z}, e2 = V3{c.x, c.y, c.z};
+            float t = h.t, u = h.u, v = h.v;
+            V3 dir = ds;
+            const V3 pc = cross3(dc, e2);
+            const float detc = dot3(e1, pc);
+            if (detc != 0.0f) {                                   // centre ray on the triangle's plane
+                const float invc = 1.0f / detc;
+                const V3 tvec = cam - v0;
+                const V3 qvec = cross3(tvec, e1);
+                u = dot3(tvec, pc) * invc;
+                v = dot3(dc, qvec) * invc;
+                t = dot3(e2, qvec) * invc;
+                dir = dc;
+            }
+            const V3 wp = cam + dir * t;
+            float vp[4];
+            mul_m4_v4(fp.view, wp.x, wp.y, wp.z, 1.0f, vp);
+            const float z = -vp[2];
+            V3 n = normalize3(cross3(e1, e2));
+            const uint32_t mesh = f2u(a.w) & 0x0fffffffu, prim = f2u(b.w), flat = f2u(c.w);
+            if (sc.mesh_has_normals[mesh]) {
+                uint32_t lo = 0, hi = sc.instance_count;
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sc.inst_first_tri[mid] <= flat) lo = mid; else hi = mid;
+                }
+                float N[9];
+                normal_matrix(sc.inst_xf + 12 * (size_t)lo, N);
+                const uint32_t ioff = sc.lut[mesh].y + 3u * prim;
+                V3 vn[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const uint32_t gi = sc.indices[ioff + q];
+                    vn[q] = world_normal(N, V3{sc.normals[3 * (size_t)gi], sc.normals[3 * (size_t)gi + 1], sc.normals[3 * (size_t)gi + 2]});
+                }
+                const float w0 = (1.0f - u) - v;
+                n = normalize3(V3{(vn[0].x * w0 + vn[1].x * u) + vn[2].x * v, (vn[0].y * w0 + vn[1].y * u) + vn[2].y * v,
+                                  (vn[0].z * w0 + vn[1].z * u) + vn[2].z * v});
+            }
+            zh = float_to_half(z);
+            e0 = float_to_half(n.x * 0.5f + 0.5f); e1h = float_to_half(n.y * 0.5f + 0.5f);
+            e2h = float_to_half(n.z * 0.5f + 0.5f); e3 = float_to_half(1.0f);
+        }
+        zsum = zsum + half_to_float(zh);
+        n0 = n0 + half_to_float(e0); n1 = n1 + half_to_float(e1h); n2 = n2 + half_to_float(e2h); n3 = n3 + half_to_float(e3);
+    }
+    const float invS = 1.0f / (float)S;
+    const uint16_t zr = float_to_half(zsum * invS);
+    if (depth) depth[o] = zr;
+    if (normal) {
+        ushort4 e;
+        e.x = float_to_half(n0 * invS); e.y = float_to_half(n1 * invS); e.z = float_to_half(n2 * invS); e.w = float_to_half(n3 * invS);
+        ((ushort4*)normal)[o] = e;
+    }
+    if (validOut) validOut[o] = half_to_float(zr) > 1e-6f ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K4/K5, streaming form: the any-hit counterpart of k_trace_q (rtao_kernels.hip).  Persistent waves pull chunks
 // of pixels; the chunk's rays live in two wave-wide LIFO queues in LDS (node items, leaf items) and every step pops
@@ -760,6 +860,19 @@ hipError_t gbuffer_launch(vkr_ctx* c, const FrameParams& fp, uint16_t* depth, ui
 {
     uint32_t tiles_x = ((uint32_t)fp.W + 15u) / 16u, tiles_y = ((uint32_t)fp.H + 15u) / 16u;
     k_gbuffer<<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, depth, normal, wp, ng, valid, tiles_x);
+    return hipGetLastError();
+}
+
+hipError_t gbuffer_msaa_launch(vkr_ctx* c, const FrameParams& fp, int samples, uint16_t* depth, uint16_t* normal, float* wp,
+                               float* ng, uint8_t* valid, hipStream_t st)
+{
+    const int set = samples == 8 ? 3 : (samples == 4 ? 2 : (samples == 2 ? 1 : 0));
+    uint32_t tiles_x = ((uint32_t)fp.W + 15u) / 16u, tiles_y = ((uint32_t)fp.H + 15u) / 16u;
+    // pixel-centre outputs (and, for one sample, everything) from the one-sample kernel
+    k_gbuffer<<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, set == 0 ? depth : nullptr, set == 0 ? normal : nullptr,
+                                                             wp, ng, set == 0 ? valid : nullptr, tiles_x);
+    if (set != 0)
+        k_gbuffer_msaa<<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, set, depth, normal, valid, tiles_x);
     return hipGetLastError();
 }
 

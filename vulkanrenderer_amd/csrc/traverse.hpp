@@ -66,7 +66,7 @@ struct SceneDev {
 
 struct HitDev { float t; uint32_t tri; float u, v; };
 
-enum { Q_AO = 0, Q_SHADOW = 1, Q_PRIMARY = 2 };
+enum { Q_AO = 0, Q_SHADOW = 1, Q_PRIMARY = 2, Q_PRIMARY_MS = 3 };
 
 struct TraceCounters { uint32_t nodes, tris, wave_node_iters, wave_tri_iters; };
 
@@ -161,10 +161,12 @@ VKR_DI void cswap(uint32_t& a, uint32_t& b)
 // MODE Q_AO      : closest committed hit, candidates filtered by class / alpha test (queryAoClosestHit)
 // MODE Q_SHADOW  : any hit, every triangle occludes (gl_RayFlagsOpaqueEXT|TerminateOnFirstHit, pbr.frag:199-215)
 // MODE Q_PRIMARY : as Q_AO, ties in t resolved towards the lower flat triangle id (G-buffer producer)
+// MODE Q_PRIMARY_MS : Q_PRIMARY for one MSAA sample: the MASK discard of a candidate is decided with the barycentrics of
+//                  the pixel-centre ray (o, dc) on the triangle's plane -- the fragment shader runs once per pixel
 // `stack` points at this lane's column of the block's LDS stack: entry k = {stack[(2k)*B], stack[(2k+1)*B]}.
 template <int MODE, bool STATS, int B = VKR_TRACE_BLOCK>
 __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float tmin, float tmax, HitDev* hit,
-                                         uint32_t* stack, TraceCounters* cnt)
+                                         uint32_t* stack, TraceCounters* cnt, V3 dc = V3{0.0f, 0.0f, 1.0f})
 {
     float tbest = tmax;
     uint32_t best_flat = 0xffffffffu, best_tri = 0xffffffffu;
@@ -247,7 +249,7 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
                 float t = dot3(e2, qvec) * inv;
                 if (!(t > tmin)) continue;
                 uint32_t flat = f2u(c.w);
-                if (MODE == Q_PRIMARY) {
+                if (MODE == Q_PRIMARY || MODE == Q_PRIMARY_MS) {
                     if (!(t < tbest || (t == tbest && flat < best_flat))) continue;
                 } else {
                     if (!(t < tbest)) continue;
@@ -256,7 +258,18 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
                     uint32_t mw = f2u(a.w);
                     uint32_t cls = mw >> 28;
                     if (cls == 1u) continue;
-                    if (cls == 2u && !alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), u, v)) continue;
+                    if (cls == 2u) {
+                        float au = u, av = v;
+                        if (MODE == Q_PRIMARY_MS) {
+                            V3 pc = cross3(dc, e2);
+                            float detc = dot3(e1, pc);
+                            if (detc == 0.0f) continue;       // plane edge-on to the centre ray: no fragment value exists
+                            float invc = 1.0f / detc;
+                            au = dot3(tvec, pc) * invc;
+                            av = dot3(dc, qvec) * invc;
+                        }
+                        if (!alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), au, av)) continue;
+                    }
                 }
                 tbest = t; best_flat = flat; best_tri = ti; bu = u; bv = v; found = true;
                 if (MODE == Q_SHADOW) { stop = true; break; }

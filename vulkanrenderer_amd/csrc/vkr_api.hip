@@ -889,6 +889,20 @@ int vkr_gbuffer_primary(vkr_ctx* c, const float ubo[VKR_UBO_FLOATS], uint16_t* d
     return VKR_OK;
 }
 
+int vkr_gbuffer_primary_msaa(vkr_ctx* c, const float ubo[VKR_UBO_FLOATS], uint32_t samples, uint16_t* depth, uint16_t* normal,
+                             float* world_pos, float* geom_normal, uint8_t* valid, void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!ubo) return fail(c, VKR_ERR_INVALID_ARG, "ubo is NULL");
+    if (samples != 1u && samples != 2u && samples != 4u && samples != 8u)
+        return fail(c, VKR_ERR_INVALID_ARG, "samples must be 1, 2, 4 or 8 (got %u)", samples);
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_gbuffer_primary_msaa before vkr_bvh_build");
+    if (int rc = set_device(c)) return rc;
+    FrameParams fp = make_frame_params(c, ubo);
+    HIP_OR_FAIL(c, gbuffer_msaa_launch(c, fp, (int)samples, depth, normal, world_pos, geom_normal, valid, (hipStream_t)stream));
+    return VKR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ counters
 int vkr_trace_stats_enable(vkr_ctx* c, int enable)
 {

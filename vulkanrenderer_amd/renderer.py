@@ -362,12 +362,17 @@ class GBuffer:
             self.valid.copy_(torch.from_numpy(valid))
 
 
-def generate_gbuffer(ctx: Context, ubo: np.ndarray, gb: GBuffer):
-    """vkr_gbuffer_primary: the DepthPrepass stand-in."""
+def generate_gbuffer(ctx: Context, ubo: np.ndarray, gb: GBuffer, samples: int = 1):
+    """vkr_gbuffer_primary[_msaa]: the DepthPrepass stand-in; samples = the prepass's MSAA count."""
     u = (C.c_float * _capi.UBO_FLOATS)(*[float(x) for x in ubo])
-    _check(ctx.handle, ctx.lib.vkr_gbuffer_primary(ctx.handle, u, _ptr(gb.linear_depth), _ptr(gb.normal),
-                                                   _ptr(gb.world_pos), _ptr(gb.geom_normal), _ptr(gb.valid),
-                                                   ctx.stream()), "vkr_gbuffer_primary")
+    if samples == 1:
+        _check(ctx.handle, ctx.lib.vkr_gbuffer_primary(ctx.handle, u, _ptr(gb.linear_depth), _ptr(gb.normal),
+                                                       _ptr(gb.world_pos), _ptr(gb.geom_normal), _ptr(gb.valid),
+                                                       ctx.stream()), "vkr_gbuffer_primary")
+    else:
+        _check(ctx.handle, ctx.lib.vkr_gbuffer_primary_msaa(ctx.handle, u, int(samples), _ptr(gb.linear_depth), _ptr(gb.normal),
+                                                            _ptr(gb.world_pos), _ptr(gb.geom_normal), _ptr(gb.valid),
+                                                            ctx.stream()), "vkr_gbuffer_primary_msaa")
 
 
 class RtaoComputePass(RenderPass):
