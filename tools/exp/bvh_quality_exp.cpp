@@ -162,6 +162,38 @@ static Tree build_two_level(int K, int radius, int radius_top)
     return t;
 }
 
+
+// hybrid 3: binned SAH on top down to ranges of <= K triangles, each range then put into Morton order and rebuilt by
+// local PLOC (what a "fast trace" GPU build would do: SAH level passes over the whole array, then the LDS treelets)
+static std::vector<uint64_t> g_mkey;   // per triangle
+static int g_one_axis = 0;
+static int sahtop_rec(Tree& t, int lo, int hi, int K, int radius)
+{
+    if (hi - lo <= K) { std::sort(t.order.begin() + lo, t.order.begin() + hi, [&](int a, int b) { return g_mkey[a] < g_mkey[b]; }); return ploc_range(t, lo, hi, radius); }
+    Box b, cb; for (int i = lo; i < hi; ++i) { b.grow(TB[t.order[i]]); cb.grow(TC[t.order[i]]); }
+    const int NB = 16; int only = -1; if (g_one_axis) { V3 e = cb.hi - cb.lo; only = e.x >= e.y && e.x >= e.z ? 0 : (e.y >= e.z ? 1 : 2); } float best = 1e30f; int bax = -1, bsp = 0;
+    for (int ax = 0; ax < 3; ++ax) { if (only >= 0 && ax != only) continue;
+        float c0 = (&cb.lo.x)[ax], c1 = (&cb.hi.x)[ax]; if (c1 - c0 < 1e-9f) continue;
+        Box bb[NB]; int bc[NB] = {0};
+        for (int i = lo; i < hi; ++i) { int k = std::min(NB - 1, (int)(((&TC[t.order[i]].x)[ax] - c0) / (c1 - c0) * NB)); bb[k].grow(TB[t.order[i]]); bc[k]++; }
+        float ra[NB]; Box acc; int cnt = 0; int rc[NB];
+        for (int k = NB - 1; k > 0; --k) { if (bc[k]) acc.grow(bb[k]); cnt += bc[k]; ra[k] = cnt ? acc.area() : 0.f; rc[k] = cnt; }
+        Box la; int lc = 0;
+        for (int k = 0; k < NB - 1; ++k) { if (bc[k]) la.grow(bb[k]); lc += bc[k]; if (lc == 0 || rc[k + 1] == 0) continue; float c = la.area() * lc + ra[k + 1] * rc[k + 1]; if (c < best) { best = c; bax = ax; bsp = k; } }
+    }
+    int mid;
+    if (bax < 0) mid = (lo + hi) >> 1;
+    else { float c0 = (&cb.lo.x)[bax], c1 = (&cb.hi.x)[bax];
+        mid = (int)(std::partition(t.order.begin() + lo, t.order.begin() + hi, [&](int i) { return std::min(NB - 1, (int)(((&TC[i].x)[bax] - c0) / (c1 - c0) * NB)) <= bsp; }) - t.order.begin());
+        if (mid == lo || mid == hi) mid = (lo + hi) >> 1; }
+    int l = sahtop_rec(t, lo, mid, K, radius), r = sahtop_rec(t, mid, hi, K, radius);
+    int id = (int)t.n.size(); t.n.emplace_back(); t.n[id].l = l; t.n[id].r = r; t.n[id].first = lo; t.n[id].count = hi - lo; t.n[id].box = b; return id;
+}
+static Tree build_sahtop(int K, int radius)
+{
+    Tree t; std::vector<int> ord; auto key = morton_sorted(ord); g_mkey.resize(T.size()); for (size_t i = 0; i < T.size(); ++i) g_mkey[ord[i]] = key[i];
+    t.order = ord; t.n.reserve(3 * T.size()); t.root = sahtop_rec(t, 0, (int)T.size(), K, radius); return t;
+}
 static Tree build_sah() { Tree t; t.order.resize(T.size()); for (size_t i = 0; i < T.size(); ++i) t.order[i] = (int)i; t.n.reserve(2 * T.size()); t.root = sah_rec(t, 0, (int)T.size()); return t; }
 
 // PLOC over Morton-sorted leaves; leaf order is rebuilt by DFS afterwards
@@ -255,21 +287,20 @@ int main(int argc, char** argv)
     if (argc > 3) LEAFMAX = atoi(argv[3]);
     auto eval = [&](const char* name, const Tree& t) { Wide W = collapse(t); uint64_t nv = 0, tt = 0; for (int i = 0; i < NR; ++i) trace(W, ro[i], rd[i], radius, nv, tt);
         printf("%-10s binary SAH %.1f  wide nodes %zu  nodes/ray %.2f  tris/ray %.2f\n", name, sah_cost(t), W.w.size(), (double)nv / NR, (double)tt / NR); fflush(stdout); };
+    bool all = argc > 4;
+    if (all) {
     { Tree t = build_lbvh(); eval("lbvh", t); }
-    { Tree t = build_hybrid(16); eval("hyb16", t); }
-    { Tree t = build_hybrid(64); eval("hyb64", t); }
-    { Tree t = build_hybrid(256); eval("hyb256", t); }
     { Tree t = build_hybrid(1024); eval("hyb1024", t); }
-    { Tree t = build_hybrid(2048); eval("hyb2048", t); }
     { Tree t = build_hybrid(4096); eval("hyb4096", t); }
-    { Tree t = build_hybrid(32768); eval("hyb32768", t); }
     { Tree t = build_hybrid2(256, 8); eval("lploc256", t); }
-    { Tree t = build_hybrid2(1024, 8); eval("lploc1024", t); }
-    { Tree t = build_hybrid2(256, 16); eval("lploc256r16", t); }
     { Tree t = build_two_level(1024, 8, 8); eval("2lvl r8", t); }
-    { Tree t = build_two_level(1024, 8, 25); eval("2lvl r25", t); }
     { Tree t = build_ploc(8); eval("ploc r8", t); }
-    { Tree t = build_ploc(25); eval("ploc r25", t); }
+    }
+    { Tree t = build_hybrid2(1024, 8); eval("lploc1024", t); }
+    { Tree t = build_sahtop(1024, 8); eval("sahtop1024", t); }
+    { g_one_axis = 1; Tree t = build_sahtop(1024, 8); eval("sahtop1024-1ax", t); g_one_axis = 0; }
+    { Tree t = build_sahtop(512, 8); eval("sahtop512", t); }
+    { Tree t = build_sahtop(256, 8); eval("sahtop256", t); }
     { Tree t = build_sah(); eval("sah16", t); }
     return 0;
 }

@@ -329,6 +329,309 @@ __global__ __launch_bounds__(256) void k_emit_sorted(BuildIn in, const uint32_t*
     o[2] = make_float4(e2.x, e2.y, e2.z, u2f(flat));
 }
 
+#ifndef VKR_TL_MAX
+#define VKR_TL_MAX 1024
+#endif
+#ifndef VKR_TL_R
+#define VKR_TL_R 8
+#endif
+constexpr int TL_MAX = VKR_TL_MAX;     // triangles per treelet = threads per block (64 .. 1024)
+constexpr int TL_MIN = 4;
+constexpr int TL_R = VKR_TL_R;         // search window (positions either side)
+constexpr int TL_WAVES = TL_MAX / 64;
+
+// ---------------------------------------------------------------- binned-SAH top levels ------------------
+// The reference asks its driver for ePreferFastTrace (RayTracingContext.cpp:237, :305).  The Karras tree splits by Morton
+// bits; this phase replaces its TOP by surface-area-heuristic splits: level by level, every range of more than TL_MAX
+// triangles is split at the best of 16 centroid bins along the widest axis of its centroid bounds (measured offline,
+// tools/exp/bvh_quality_exp.cpp: one axis is as good as three; -11 % node visits per AO ray on top of the treelets).
+// Nothing is moved while the levels run: a triangle only carries the id of its current range and the left/right path that
+// led there.  At the end the path becomes the leading bits of the sort key (followed by the Morton bits), four more
+// radix passes over the top 32 bits re-sort the array stably, and the unchanged Karras kernel then reproduces the SAH
+// splits from the path bits and goes on by Morton bits below them -- where the treelet rebuild takes over.  A range
+// that cannot be split (coincident centroids, depth 32) simply keeps its path and is left to the Morton bits.
+#ifndef VKR_SAH_LEAF
+#define VKR_SAH_LEAF VKR_TL_MAX
+#endif
+#ifndef VKR_SAH_BINS
+#define VKR_SAH_BINS 16
+#endif
+constexpr int SAH_LEAF = VKR_SAH_LEAF;       // ranges of more triangles than this are split further (<= TL_MAX)
+constexpr int SAH_BINS = VKR_SAH_BINS;
+constexpr int SAH_DEPTH = 32;                 // path bits
+constexpr uint32_t SAH_FINAL = 0xffffffffu;
+constexpr int SAH_CHUNK = 1024;               // triangles per k_sah_bin block
+constexpr int SAH_WORDS = 13;                // per bin: count, box ~enc(lo.xyz) enc(hi.xyz), centroids ~enc(min.xyz) enc(max.xyz)
+constexpr int SAH_BIN_WORDS = SAH_BINS * SAH_WORDS;   // all words grow from 0 (atomicAdd / atomicMax)
+
+struct SahNode {
+    uint32_t cmin[3], cmax[3];   // centroid bounds as ~enc_f(min), enc_f(max): both grown with atomicMax from 0
+    int32_t axis;                // split axis; -1 = not split
+    int32_t ksplit;              // bins <= ksplit go left
+    uint32_t child[2];           // id among the next level's ranges, or SAH_FINAL
+    uint32_t pad[2];
+};
+
+VKR_DI int sah_axis(const SahNode& nd, float& c0, float& inv)
+{
+    const float l0 = dec_f(~nd.cmin[0]), l1 = dec_f(~nd.cmin[1]), l2 = dec_f(~nd.cmin[2]);
+    const float e0 = dec_f(nd.cmax[0]) - l0, e1 = dec_f(nd.cmax[1]) - l1, e2 = dec_f(nd.cmax[2]) - l2;
+    float e = e0, l = l0;      // widest axis, ties to the lower one (written as updates: the nested-select form crashes
+    int a = 0;                 // hipcc 7.2's instruction selection)
+    if (e1 > e) { e = e1; l = l1; a = 1; }
+    if (e2 > e) { e = e2; l = l2; a = 2; }
+    c0 = l;
+    inv = (float)SAH_BINS / e;
+    return (e > 0.0f && e < 3.0e38f) ? a : -1;
+}
+VKR_DI int sah_bin(float c, float c0, float inv)
+{
+    const float s = (c - c0) * inv;
+    return s > 0.0f ? (s < (float)(SAH_BINS - 1) ? (int)s : SAH_BINS - 1) : 0;   // NaN -> 0
+}
+
+// triangle boxes in Morton order + per-triangle state; thread 0 seeds level 0 with the whole array as one range
+__global__ __launch_bounds__(256) void k_sah_prep(BuildIn in, const uint32_t* perm, float4* box, uint32_t* tnode, uint32_t* path,
+                                                  uint8_t* depth, SahNode* nodes0, const BvhBounds* bnd, uint32_t* level_count)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0u) {
+        SahNode r;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r.cmin[k] = ~bnd->cen_min[k]; r.cmax[k] = bnd->cen_max[k]; }
+        r.axis = -1; r.ksplit = 0; r.child[0] = r.child[1] = SAH_FINAL; r.pad[0] = r.pad[1] = 0u;
+        nodes0[0] = r;
+        level_count[0] = 1u;
+    }
+    if (i >= in.tri_count) return;
+    const TriW t = emit_tri(in, perm[i]);
+    box[2u * i] = make_float4(__builtin_fminf(t.v0.x, __builtin_fminf(t.v1.x, t.v2.x)), __builtin_fminf(t.v0.y, __builtin_fminf(t.v1.y, t.v2.y)),
+                              __builtin_fminf(t.v0.z, __builtin_fminf(t.v1.z, t.v2.z)), 0.0f);
+    box[2u * i + 1u] = make_float4(__builtin_fmaxf(t.v0.x, __builtin_fmaxf(t.v1.x, t.v2.x)), __builtin_fmaxf(t.v0.y, __builtin_fmaxf(t.v1.y, t.v2.y)),
+                                   __builtin_fmaxf(t.v0.z, __builtin_fmaxf(t.v1.z, t.v2.z)), 0.0f);
+    tnode[i] = 0u; path[i] = 0u; depth[i] = 0;
+}
+
+// A: bin the triangles of every open range.  Every bin word is a count or a maximum (minima are stored complemented), so
+// lanes that fall into the same (range, bin) -- in Morton order that is most of a wave -- are first combined in the wave
+// and one lane issues the atomics.  Each block keeps LDS bins for the range of its first triangle; other ranges go to
+// the global bins directly.
+VKR_DI uint32_t wave_umax(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_sah_bin(uint32_t n, const uint32_t* tnode, const float4* box, const SahNode* nodes,
+                                                 const uint32_t* level_count, uint32_t* bins)
+{
+    if (*level_count == 0u) return;
+    __shared__ uint32_t s_bins[SAH_BIN_WORDS];
+    __shared__ uint32_t s_node;
+    const uint32_t base = blockIdx.x * (uint32_t)SAH_CHUNK;
+    if (threadIdx.x == 0) s_node = tnode[base];
+    for (int w = threadIdx.x; w < SAH_BIN_WORDS; w += 256) s_bins[w] = 0u;
+    __syncthreads();
+    const uint32_t mine = s_node;
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < SAH_CHUNK / 256; ++j) {
+        const uint32_t i = base + (uint32_t)j * 256u + threadIdx.x;
+        uint32_t nd = i < n ? tnode[i] : SAH_FINAL;
+        uint32_t v[SAH_WORDS - 1];
+#pragma unroll
+        for (int q = 0; q < SAH_WORDS - 1; ++q) v[q] = 0u;
+        int k = 0;
+        if (nd != SAH_FINAL) {
+            const SahNode node = nodes[nd];
+            float c0, inv;
+            const int a = sah_axis(node, c0, inv);
+            if (a < 0) nd = SAH_FINAL;
+            else {
+                const float4 lo = box[2u * i], hi = box[2u * i + 1u];
+                const float cx = (lo.x + hi.x) * 0.5f, cy = (lo.y + hi.y) * 0.5f, cz = (lo.z + hi.z) * 0.5f;
+                k = sah_bin(a == 0 ? cx : (a == 1 ? cy : cz), c0, inv);
+                v[0] = ~enc_f(lo.x); v[1] = ~enc_f(lo.y); v[2] = ~enc_f(lo.z);
+                v[3] = enc_f(hi.x); v[4] = enc_f(hi.y); v[5] = enc_f(hi.z);
+                v[6] = ~enc_f(cx); v[7] = ~enc_f(cy); v[8] = ~enc_f(cz);
+                v[9] = enc_f(cx); v[10] = enc_f(cy); v[11] = enc_f(cz);
+            }
+        }
+        bool act = nd != SAH_FINAL;
+        const uint32_t key = nd * (uint32_t)SAH_BINS + (uint32_t)k;
+        for (int round = 0; round < 4; ++round) {                  // up to four distinct (range, bin) pairs are combined
+            const unsigned long long mask = __ballot(act);
+            if (mask == 0ull) break;
+            const int leader = __ffsll((long long)mask) - 1;
+            const uint32_t lkey = (uint32_t)__shfl((int)key, leader, 64);
+            const bool match = act && key == lkey;
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(match));
+            uint32_t r[SAH_WORDS - 1];
+#pragma unroll
+            for (int q = 0; q < SAH_WORDS - 1; ++q) r[q] = wave_umax(match ? v[q] : 0u);
+            if (lane == leader) {
+                if (nd == mine) {
+                    atomicAdd(&s_bins[k * SAH_WORDS], cnt);
+#pragma unroll
+                    for (int q = 0; q < SAH_WORDS - 1; ++q) atomicMax(&s_bins[k * SAH_WORDS + 1 + q], r[q]);
+                } else {
+                    uint32_t* b = bins + (size_t)key * SAH_WORDS;
+                    atomicAdd(b, cnt);
+#pragma unroll
+                    for (int q = 0; q < SAH_WORDS - 1; ++q) atomicMax(b + 1 + q, r[q]);
+                }
+            }
+            act = act && !match;
+        }
+        if (act) {                                                  // a wave that straddles many bins: the rest one by one
+            if (nd == mine) {
+                atomicAdd(&s_bins[k * SAH_WORDS], 1u);
+#pragma unroll
+                for (int q = 0; q < SAH_WORDS - 1; ++q) atomicMax(&s_bins[k * SAH_WORDS + 1 + q], v[q]);
+            } else {
+                uint32_t* b = bins + (size_t)key * SAH_WORDS;
+                atomicAdd(b, 1u);
+#pragma unroll
+                for (int q = 0; q < SAH_WORDS - 1; ++q) atomicMax(b + 1 + q, v[q]);
+            }
+        }
+    }
+    __syncthreads();
+    if (mine != SAH_FINAL) {
+        for (int w = threadIdx.x; w < SAH_BIN_WORDS; w += 256) {
+            const uint32_t v = s_bins[w];
+            if (v) {
+                uint32_t* dst = bins + (size_t)mine * SAH_BIN_WORDS + w;
+                if (w % SAH_WORDS == 0) atomicAdd(dst, v); else atomicMax(dst, v);
+            }
+        }
+    }
+}
+
+VKR_DI float sah_half_area(const float lo[3], const float hi[3])
+{
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return ex * ey + ey * ez + ez * ex;
+}
+
+// B: one thread per open range picks the split and opens the children that are still too large; their centroid bounds
+// come from the bins
+__global__ __launch_bounds__(64) void k_sah_split(SahNode* cur, SahNode* next, const uint32_t* bins, uint32_t* level_count, int level)
+{
+    const uint32_t id = blockIdx.x * 64u + threadIdx.x;
+    if (id >= level_count[0]) return;
+    const SahNode nd = cur[id];
+    float c0, inv;
+    const int a = sah_axis(nd, c0, inv);
+    int best_k = -1;
+    uint32_t best_lc = 0u, total = 0u;
+    const uint32_t* b = bins + (size_t)id * SAH_BIN_WORDS;
+    if (a >= 0) {
+        float ra[SAH_BINS];
+        uint32_t rc[SAH_BINS];
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        uint32_t cnt = 0u;
+#pragma unroll
+        for (int k = SAH_BINS - 1; k >= 1; --k) {
+            const uint32_t ck = b[k * SAH_WORDS];
+            if (ck) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    lo[q] = __builtin_fminf(lo[q], dec_f(~b[k * SAH_WORDS + 1 + q]));
+                    hi[q] = __builtin_fmaxf(hi[q], dec_f(b[k * SAH_WORDS + 4 + q]));
+                }
+            }
+            cnt += ck;
+            rc[k] = cnt;
+            ra[k] = cnt ? sah_half_area(lo, hi) : 0.0f;
+        }
+        total = cnt + b[0];
+        float llo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, lhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        uint32_t lc = 0u;
+        float best = 3.0e38f;
+#pragma unroll
+        for (int k = 0; k < SAH_BINS - 1; ++k) {
+            const uint32_t ck = b[k * SAH_WORDS];
+            if (ck) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    llo[q] = __builtin_fminf(llo[q], dec_f(~b[k * SAH_WORDS + 1 + q]));
+                    lhi[q] = __builtin_fmaxf(lhi[q], dec_f(b[k * SAH_WORDS + 4 + q]));
+                }
+            }
+            lc += ck;
+            if (lc == 0u || rc[k + 1] == 0u) continue;
+            const float cost = sah_half_area(llo, lhi) * (float)lc + ra[k + 1] * (float)rc[k + 1];
+            if (cost < best) { best = cost; best_k = k; best_lc = lc; }
+        }
+    }
+    if (best_k < 0) { cur[id].axis = -1; return; }
+    const uint32_t cnt2[2] = {best_lc, total - best_lc};
+    uint32_t child[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        child[s] = SAH_FINAL;
+        if (cnt2[s] > (uint32_t)SAH_LEAF && level + 1 < SAH_DEPTH) {
+            const uint32_t cid = atomicAdd(&level_count[1], 1u);
+            SahNode z;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { z.cmin[q] = 0u; z.cmax[q] = 0u; }
+            const int k0 = s == 0 ? 0 : best_k + 1, k1 = s == 0 ? best_k : SAH_BINS - 1;
+            for (int k = k0; k <= k1; ++k) {
+                if (b[k * SAH_WORDS] == 0u) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const uint32_t mn = b[k * SAH_WORDS + 7 + q], mx = b[k * SAH_WORDS + 10 + q];
+                    z.cmin[q] = z.cmin[q] > mn ? z.cmin[q] : mn;
+                    z.cmax[q] = z.cmax[q] > mx ? z.cmax[q] : mx;
+                }
+            }
+            z.axis = -1; z.ksplit = 0; z.child[0] = z.child[1] = SAH_FINAL; z.pad[0] = z.pad[1] = 0u;
+            next[cid] = z;
+            child[s] = cid;
+        }
+    }
+    cur[id].axis = a;
+    cur[id].ksplit = best_k;
+    cur[id].child[0] = child[0];
+    cur[id].child[1] = child[1];
+}
+
+// C: every triangle of a split range takes its side: one more path bit and the child's id
+__global__ __launch_bounds__(256) void k_sah_assign(uint32_t n, uint32_t* tnode, const float4* box, uint32_t* path, uint8_t* depth,
+                                                    const SahNode* cur, const uint32_t* level_count)
+{
+    if (*level_count == 0u) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nd = tnode[i];
+    if (nd == SAH_FINAL) return;
+    const SahNode node = cur[nd];
+    uint32_t child = SAH_FINAL;
+    if (node.axis >= 0) {
+        float c0, inv;
+        const int a = sah_axis(node, c0, inv);
+        const float4 lo = box[2u * i], hi = box[2u * i + 1u];
+        const float c = a == 0 ? (lo.x + hi.x) * 0.5f : (a == 1 ? (lo.y + hi.y) * 0.5f : (lo.z + hi.z) * 0.5f);
+        const int k = sah_bin(c, c0, inv);
+        const uint32_t side = k > node.ksplit ? 1u : 0u;
+        path[i] = (path[i] << 1) | side;
+        depth[i] = (uint8_t)(depth[i] + 1);
+        child = side ? node.child[1] : node.child[0];
+    }
+    tnode[i] = child;
+}
+
+// the path in front of the (left-justified) Morton bits
+__global__ __launch_bounds__(256) void k_sah_rekey(uint32_t n, uint64_t* keys, const uint32_t* path, const uint8_t* depth, int key_bits)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t m = keys[i] << (64 - key_bits);
+    const uint32_t d = depth[i];
+    keys[i] = d ? (((uint64_t)path[i] << (64u - d)) | (m >> d)) : m;
+}
+
 // ---------------------------------------------------------------- Karras 2012 hierarchy ------------------
 VKR_DI int delta(const uint64_t* keys, int n, int i, int j)
 {
@@ -380,16 +683,7 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint64_t* keys, int n, 
 // internal nodes reuse the range's own Karras indices ({a..b} minus the end the root does not sit on); triangles are
 // permuted inside the range into the DFS order of the new subtree, so every subtree still owns a contiguous range.
 // Runs between k_emit_sorted and k_fit: boxes and heights come from the fit, as before.
-#ifndef VKR_TL_MAX
-#define VKR_TL_MAX 1024
-#endif
-#ifndef VKR_TL_R
-#define VKR_TL_R 8
-#endif
-constexpr int TL_MAX = VKR_TL_MAX;     // triangles per treelet = threads per block (64 .. 1024)
-constexpr int TL_MIN = 4;
-constexpr int TL_R = VKR_TL_R;         // search window (positions either side)
-constexpr int TL_WAVES = TL_MAX / 64;
+
 
 __global__ __launch_bounds__(256) void k_treelet_roots(const uint2* bin_range, const uint32_t* node_parent, int n_internal,
                                                        uint32_t* list)   // [0] = count, [1] = work counter, [2..] = roots
@@ -986,6 +1280,36 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
                                                         c->d_vals[cur ^ 1].p, n, shift, ntiles, c->d_hist.p,
                                                         c->d_digit_totals.p);
             cur ^= 1;
+        }
+        if (c->sah_top && n > (uint32_t)SAH_LEAF) {
+            const size_t cap = (size_t)n / SAH_LEAF + 2;                       // open ranges per level: each holds > SAH_LEAF triangles
+            const size_t w_depth = ((size_t)n + 3) / 4, w_nodes = cap * (sizeof(SahNode) / 4);
+            const size_t words = 2 * (size_t)n + w_depth + 64 + 2 * w_nodes + cap * SAH_BIN_WORDS;
+            if (c->d_sah.n < words) VKR_TRY(c->d_sah.alloc(words));
+            uint32_t* tnode = c->d_sah.p;
+            uint32_t* path = tnode + n;
+            uint8_t* depth = (uint8_t*)(path + n);
+            uint32_t* level_count = path + n + w_depth;                        // [SAH_DEPTH + 1] used
+            SahNode* nodes[2] = {(SahNode*)(level_count + 64), (SahNode*)(level_count + 64 + w_nodes)};
+            uint32_t* bins = level_count + 64 + 2 * w_nodes;
+            float4* box = (float4*)c->d_deposit.p;                             // 2 float4 per triangle; the fit's slots are free until k_fit
+            VKR_TRY(hipMemsetAsync(level_count, 0, 64 * 4, st));
+            k_sah_prep<<<nb, 256, 0, st>>>(in, c->d_vals[cur].p, box, tnode, path, depth, nodes[0], c->d_bounds.p, level_count);
+            for (int level = 0; level < SAH_DEPTH; ++level) {
+                VKR_TRY(hipMemsetAsync(bins, 0, cap * SAH_BIN_WORDS * 4, st));
+                k_sah_bin<<<(n + SAH_CHUNK - 1) / SAH_CHUNK, 256, 0, st>>>(n, tnode, box, nodes[level & 1], level_count + level, bins);
+                k_sah_split<<<(uint32_t)((cap + 63) / 64), 64, 0, st>>>(nodes[level & 1], nodes[(level + 1) & 1], bins, level_count + level, level);
+                k_sah_assign<<<nb, 256, 0, st>>>(n, tnode, box, path, depth, nodes[level & 1], level_count + level);
+            }
+            k_sah_rekey<<<nb, 256, 0, st>>>(n, c->d_keys[cur].p, path, depth, key_bits);
+            for (int shift = 32; shift < 64; shift += 8) {                     // stable: the Morton order survives inside equal paths
+                k_rs_hist<<<ntiles, RS_THREADS, 0, st>>>(c->d_keys[cur].p, n, shift, ntiles, c->d_hist.p);
+                k_rs_scan<<<256, RS_THREADS, 0, st>>>(c->d_hist.p, ntiles, c->d_digit_totals.p);
+                k_rs_scatter<<<ntiles, RS_THREADS, 0, st>>>(c->d_keys[cur].p, c->d_vals[cur].p, c->d_keys[cur ^ 1].p,
+                                                            c->d_vals[cur ^ 1].p, n, shift, ntiles, c->d_hist.p,
+                                                            c->d_digit_totals.p);
+                cur ^= 1;
+            }
         }
         VKR_TRY(hipMemcpyAsync(c->d_perm.p, c->d_vals[cur].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         if (n > 1)

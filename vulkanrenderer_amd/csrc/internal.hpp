@@ -125,6 +125,8 @@ struct vkr_ctx {
     bool treelets = true;      // range-local PLOC rebuild of the small subtrees (k_treelet_ploc)
     bool validate_tree = false; // VKR_VALIDATE_TREE=1: host-side check of the binary tree before the fit walks it
     vkr::DevBuf<uint32_t> d_treelet;   // [0] root count, [1] work counter, [2..] treelet roots
+    bool sah_top = true;       // binned-SAH splits for ranges above the treelet size (k_sah_*), else Morton splits all the way
+    vkr::DevBuf<uint32_t> d_sah;       // per-triangle range id / path / depth, per-level range records and bins
     vkr::DevBuf<float4> d_nodes;             // 4 x float4 per wide node (traverse.hpp)
     vkr::DevBuf<uint4> d_wide_bref;          // per wide node: binary refs of its children (refit only)
     vkr::DevBuf<int2> d_bin_child;           // binary LBVH (build/refit only)

@@ -119,6 +119,7 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     // experiment switches (development only; defaults are the shipped configuration)
     if (const char* e = getenv("VKR_MORTON_EMC")) c->morton_emc = (e[0] == '1');
     if (const char* e = getenv("VKR_TREELETS")) c->treelets = (e[0] != '0');            // "0" = plain Karras tree
+    if (const char* e = getenv("VKR_SAH_TOP")) c->sah_top = (e[0] != '0');              // "0" = Morton splits above the treelets
     if (const char* e = getenv("VKR_VALIDATE_TREE")) c->validate_tree = (e[0] == '1');
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
     if (const char* e = getenv("VKR_SUN_MODE")) c->sun_packets = (e[0] != 'r');         // "ray" = one queue item per ray
@@ -165,7 +166,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
     c->d_ib_infos.release(); c->d_ib_bounds.release(); c->d_ib_flags.release(); c->d_ib_tile.release();
     c->d_ib_counters.release(); c->d_ib_seg_begin.release(); c->d_ib_seg_rank.release(); c->d_ib_spans.release();
-    c->d_ib_order.release(); c->d_ibl_tables.release(); c->d_treelet.release();
+    c->d_ib_order.release(); c->d_ibl_tables.release(); c->d_treelet.release(); c->d_sah.release();
     delete c;
 }
 
@@ -372,18 +373,22 @@ int vkr_bvh_build(vkr_ctx* c, void* stream)
     // 21 bits/axis with the treelet rebuild; if the wide tree comes out deeper than the traversal stack allows, first
     // drop the treelets (clustering has no depth bound), then fall back to 10 bits/axis, where the index tie-break of
     // the Karras tree bounds the height by 30 + log2(n) (pathological duplicate centroids).
-    const uint32_t tries[3] = {21u, 21u, 10u};
-    const bool want_treelets = c->treelets;
-    for (int t = 0; t < 3; ++t) {
-        if (t == 1 && !want_treelets) continue;                  // same configuration as try 0
+    // Try 0 additionally puts binned-SAH splits on top (no depth bound either); it is skipped when switched off.
+    const uint32_t tries[4] = {21u, 21u, 21u, 10u};
+    const bool want_treelets = c->treelets, want_sah = c->sah_top;
+    for (int t = 0; t < 4; ++t) {
+        if (t == 0 && !want_sah) continue;
+        if (t == 2 && !want_treelets) continue;                  // same configuration as try 1
         c->morton_bits = tries[t];
-        c->treelets = want_treelets && t == 0;
+        c->sah_top = want_sah && t == 0;
+        c->treelets = want_treelets && t <= 1;
         hipError_t be = bvh_build_launch(c, false, st);
-        if (be != hipSuccess) { c->treelets = want_treelets; HIP_OR_FAIL(c, be); }
+        if (be != hipSuccess) { c->treelets = want_treelets; c->sah_top = want_sah; HIP_OR_FAIL(c, be); }
         // the binary height bounds the number of BFS levels of the collapse; it is one word
-        if (int rc = read_height_and_bounds(c, st)) { c->treelets = want_treelets; return rc; }
+        if (int rc = read_height_and_bounds(c, st)) { c->treelets = want_treelets; c->sah_top = want_sah; return rc; }
         hipError_t we = bvh_wide_launch(c, c->bvh_height, st);
         c->treelets = want_treelets;
+        c->sah_top = want_sah;
         HIP_OR_FAIL(c, we);
         uint32_t ctl[4] = {0, 0, 0, 0};
         HIP_OR_FAIL(c, hipMemcpyAsync(ctl, c->d_wide_ctl.p, 16, hipMemcpyDeviceToHost, st));
