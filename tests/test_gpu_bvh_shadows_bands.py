@@ -121,18 +121,24 @@ def test_bvh_structure_after_build_and_refit(torch_mod):
     ctx.close()
 
 
-@pytest.mark.parametrize("kind", ["tiny", "duplicates", "coplanar_grid", "street", "treelets_off"])
+@pytest.mark.parametrize("kind", ["tiny", "duplicates", "coplanar_grid", "street", "treelets_off", "many_duplicates", "line",
+                                  "sah_off"])
 def test_treelet_rebuild_keeps_the_tree_well_formed(torch_mod, oracle_mod, kind, monkeypatch):
     """k_treelet_ploc under VKR_VALIDATE_TREE=1 (host-side check of the binary tree before the fit walks it) on the
     inputs that stress it: fewer triangles than a treelet, hundreds of identical triangles (every union area ties),
     a regular coplanar grid (ties between different pairs), a normal scene; then the wide tree's structure and one
-    traced frame against the oracle.  VKR_TREELETS=0 (plain Karras tree) must give the same pixels."""
+    traced frame against the oracle.  VKR_TREELETS=0 (plain Karras tree) must give the same pixels.  The binned-SAH top
+    levels (k_sah_*, ranges above 1024 triangles) see: the grid and the street, thousands of coincident centroids (no
+    split exists: the range is left to the Morton bits), centroids on one line (two degenerate axes), and
+    VKR_SAH_TOP=0."""
     from vulkanrenderer_amd import FrameState, make_street_scene
     from vulkanrenderer_amd.renderer import PassExecuteContext, RtaoComputePass
     from vulkanrenderer_amd.scenes import Material, Mesh, SceneData, grid_mesh, trs, VERTEX_FLOATS
     monkeypatch.setenv("VKR_VALIDATE_TREE", "1")
     if kind == "treelets_off":
         monkeypatch.setenv("VKR_TREELETS", "0")
+    if kind == "sah_off":
+        monkeypatch.setenv("VKR_SAH_TOP", "0")
     if kind == "tiny":
         scene = SceneData([grid_mesh(1, 2, 0)], [Material()], np.zeros(2, dtype=np.uint32),
                           np.stack([trs((0, 0, 3), (4, 1, 4)), trs((0.5, 0.7, 3.5), (1, 1, 1))]).astype(np.float32), "tiny")   # 8 triangles
@@ -143,6 +149,16 @@ def test_treelet_rebuild_keeps_the_tree_well_formed(torch_mod, oracle_mod, kind,
     elif kind == "coplanar_grid":
         scene = SceneData([grid_mesh(40, 40, 0)], [Material()], np.zeros(2, dtype=np.uint32),
                           np.stack([trs((-4, 0, 1), (8, 1, 8)), trs((-1, 0.8, 3), (2, 1, 2))]).astype(np.float32), "grid")     # 6400 triangles
+    elif kind == "many_duplicates":
+        g = grid_mesh(1, 1, 0)
+        xf = np.stack([trs((0, 0, 3), (4, 1, 4))] * 1300 + [trs((0.5, 0.6, 3.5), (1, 1, 1))] * 40 +
+                      [trs((-2 + 0.01 * i, 0.3, 2.0), (0.5, 1, 0.5)) for i in range(300)]).astype(np.float32)
+        scene = SceneData([g], [Material()], np.zeros(len(xf), dtype=np.uint32), xf, "manydups")                              # 3280 triangles
+    elif kind == "line":
+        g = grid_mesh(1, 1, 0)
+        xf = np.stack([trs((-4 + 8.0 * i / 1499, 0.2, 3.0), (0.05, 1, 0.05)) for i in range(1500)] +
+                      [trs((0, 0, 3), (4, 1, 4))]).astype(np.float32)
+        scene = SceneData([g], [Material()], np.zeros(len(xf), dtype=np.uint32), xf, "line")                                  # 3002 triangles
     else:
         scene = make_street_scene(5, 0.02, "bvh")
     scene.cameras = scene.cameras or [((0.3, 2.5, -1.0), (0.2, 0.0, 4.0))]
