@@ -293,6 +293,7 @@ struct ShadowArgs {
     float sunRadius, sampleCountF;
     V3 lightPos;          // point
     float* out;
+    unsigned long long* stats;   // development counters (-DVKR_SUN_STATS builds only), else unused
 };
 
 template <int MODE>
@@ -555,14 +556,22 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
 // packet only changes which boxes are opened (a superset).  Same queue machinery as k_shadow_q; a pixel whose n rays
 // are all occluded is dropped.  Node work falls ~n-fold, leaf work per hit triangle rises ~n/2-fold.
 // ---------------------------------------------------------------------------------------------
-constexpr int SP_PIX = 256;            // pixels per chunk (4 per lane)
-constexpr int SP_NQ = 768;
+#ifndef VKR_SP_PIX
+#define VKR_SP_PIX 64
+#endif
+#ifndef VKR_SP_NQ
+#define VKR_SP_NQ 768
+#endif
+constexpr int SP_PIX = VKR_SP_PIX;     // pixels per chunk at most (64, 128 or 256)
+constexpr int SP_NQ = VKR_SP_NQ;
+constexpr int SP_TQ = 64 + 64 * VKR_LEAF_MAX;   // a leaf step runs with < 64 triangle items queued and adds <= 64 * VKR_LEAF_MAX
 
 struct SunFrame {                      // written by k_sun_setup, read with scalar loads
     float dir[16][4];                  // sample directions (pbr.frag:255), w unused
     float idlo[4], idhi[4];            // per axis: bounds of 1/d over the samples (valid where axis_ok)
     uint32_t axis_ok[4];               // all samples have the same non-zero sign on this axis
     uint32_t n, hard, no_light, pad;
+    float axis[4];                     // cone around the samples: unit axis (= normalize(L)), w = tan of the half angle, padded
 };
 
 __global__ void k_sun_setup(V3 L, float sunRadius, float sampleCountF, SunFrame* out)
@@ -602,6 +611,17 @@ __global__ void k_sun_setup(V3 L, float sunRadius, float sampleCountF, SunFrame*
     }
     out->axis_ok[3] = 0; out->idlo[3] = 0; out->idhi[3] = 0;
     out->n = (uint32_t)n; out->hard = hard ? 1u : 0u; out->no_light = no_light ? 1u : 0u; out->pad = 0;
+    // bounding cone of the n directions (leaf pre-filter): tan of the largest angle to the axis, from the perpendicular part
+    float tan_max = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const V3 d = V3{out->dir[k][0], out->dir[k][1], out->dir[k][2]};
+        const float c = dot3(d, rayDir);
+        const V3 pp = d - rayDir * c;
+        const float t = (c > 1e-3f) ? __builtin_sqrtf(dot3(pp, pp)) / c : 3.0e38f;
+        tan_max = __builtin_fmaxf(tan_max, t);
+    }
+    out->axis[0] = rayDir.x; out->axis[1] = rayDir.y; out->axis[2] = rayDir.z;
+    out->axis[3] = tan_max * 1.001f + 1e-6f;
 }
 
 __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs sa, const SunFrame* __restrict__ sf,
@@ -614,6 +634,8 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
     __shared__ uint16_t s_lqp[KQ_LQ];      // ... and its pixel
     __shared__ uint32_t s_mask[SP_PIX];    // per pixel: bit k = sample k is occluded
     __shared__ float4 s_org[SP_PIX];       // per pixel: ray origin
+    __shared__ uint32_t s_tq[SP_TQ];       // triangle items (leaf triangles that passed the cone pre-filter): triangle ...
+    __shared__ uint16_t s_tqp[SP_TQ];      // ... and its pixel
 
     const int lane = threadIdx.x;
     const char* node_base = (const char*)sc.nodes;
@@ -627,6 +649,11 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
     const float ilx = sf->idlo[0], ihx = sf->idhi[0], ily = sf->idlo[1], ihy = sf->idhi[1], ilz = sf->idlo[2], ihz = sf->idhi[2];
     // near/far plane per axis by the (common) direction sign
     const bool posx = ihx > 0.0f, posy = ihy > 0.0f, posz = ihz > 0.0f;
+#ifdef VKR_SUN_STATS
+    unsigned long long st_node = 0, st_pre = 0, st_tri = 0, st_wnode = 0, st_wtri = 0, st_pix = 0;
+#endif
+    const V3 cone_axis = V3{sf->axis[0], sf->axis[1], sf->axis[2]};
+    const float cone_tan = sf->axis[3];
 
     for (;;) {
         uint32_t chunk = 0;
@@ -636,7 +663,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
         const uint32_t pix0 = chunk * pix_per_chunk;
 
         // ------------------------------------------------------------------ phase 1: origins
-        uint32_t nq = 0, lq = 0;
+        uint32_t nq = 0, lq = 0, tq = 0;
         for (int j = 0; j < (int)(pix_per_chunk / 64u); ++j) {
             const uint32_t p = (uint32_t)j * 64u + (uint32_t)lane;
             const uint32_t i = pix0 + p;
@@ -649,6 +676,9 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                     V3 rayOrigin = worldPos + geomNormal * 0.002f;                // :224-225
                     s_org[p] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
                     live = true;
+#ifdef VKR_SUN_STATS
+                    st_pix++;
+#endif
                 }
             }
             s_mask[p] = live ? 0u : 0x80000000u;     // bit 31: no rays from this pixel
@@ -659,34 +689,31 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
 
         // ------------------------------------------------------------------ phase 2: queues
         for (;;) {
-            if (lq >= 64u || (lq > 0u && nq == 0u)) {
-                // ---------------- leaf step: every triangle of the leaf against all n directions
-                const uint32_t n = lq < 64u ? lq : 64u;
-                lq -= n;
-                uint32_t cntT = 0, first = 0, pix = 0, have = 0;
-                V3 ro = v3(0, 0, 0);
+            if (tq >= 64u || (tq > 0u && lq == 0u && nq == 0u)) {
+                // ---------------- triangle step: <= 64 (pixel, triangle) items, each against all n directions
+                const uint32_t n = tq < 64u ? tq : 64u;
+                tq -= n;
+#ifdef VKR_SUN_STATS
+                if (lane == 0) st_wtri++;
+#endif
                 if ((uint32_t)lane < n) {
-                    const uint32_t ref = s_lq[lq + (uint32_t)lane];
-                    pix = (uint32_t)s_lqp[lq + (uint32_t)lane];
-                    have = s_mask[pix];
+                    const uint32_t tri = s_tq[tq + (uint32_t)lane];
+                    const uint32_t pix = (uint32_t)s_tqp[tq + (uint32_t)lane];
+                    const uint32_t have = s_mask[pix];
                     if ((have & full) != full) {
-                        const uint32_t x = ~ref;
-                        first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
+#ifdef VKR_SUN_STATS
+                        st_tri++;
+#endif
                         const float4 o = s_org[pix];
-                        ro = V3{o.x, o.y, o.z};
-                    }
-                }
-                uint32_t got = 0;
-                for (uint32_t j = 0; j < (uint32_t)VKR_LEAF_MAX; ++j) {
-                    if (__ballot(j < cntT) == 0ull) break;
-                    if (j < cntT) {
-                        const float4* tp = (const float4*)(tri_base + (size_t)(first + j) * 48u);
+                        const V3 ro = V3{o.x, o.y, o.z};
+                        const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
                         const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
                         const V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
                         // tri_hit() with its direction-independent terms hoisted: same operations, same bits per ray
                         const V3 tvec = ro - v0;
                         const V3 qvec = cross3(tvec, e1);
                         const float te = dot3(e2, qvec);
+                        uint32_t got = 0;
                         for (uint32_t k = 0; k < n_dirs; ++k) {
                             const V3 d = V3{sf->dir[k][0], sf->dir[k][1], sf->dir[k][2]};
                             const V3 pvec = cross3(d, e2);
@@ -699,9 +726,56 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                                              (t > tmin && t < tmax);
                             got |= hit ? (1u << k) : 0u;
                         }
+                        if (got & ~have) atomicOr(&s_mask[pix], got);
                     }
                 }
-                if (got & ~have) atomicOr(&s_mask[pix], got);
+                continue;
+            }
+            if (lq >= 64u || (lq > 0u && nq == 0u)) {
+                // ---------------- leaf step: the leaf's triangles against the bounding cone of the n directions; the ones
+                // that may be hit become triangle items (the exact test then runs on full waves of them).  The filter is
+                // conservative: a triangle is dropped only if its bounding sphere (centre c, radius r) lies outside the
+                // cone {perp <= h+ * tan}: every point of the sphere has perp >= perp(c) - r and h <= h(c) + r.
+                const uint32_t n = lq < 64u ? lq : 64u;
+                lq -= n;
+                uint32_t cntT = 0, first = 0, pix = 0;
+                V3 ro = v3(0, 0, 0);
+                if ((uint32_t)lane < n) {
+                    const uint32_t ref = s_lq[lq + (uint32_t)lane];
+                    pix = (uint32_t)s_lqp[lq + (uint32_t)lane];
+                    if ((s_mask[pix] & full) != full) {
+                        const uint32_t x = ~ref;
+                        first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
+                        const float4 o = s_org[pix];
+                        ro = V3{o.x, o.y, o.z};
+                    }
+                }
+                for (uint32_t j = 0; j < (uint32_t)VKR_LEAF_MAX; ++j) {
+                    if (__ballot(j < cntT) == 0ull) break;
+                    bool keep = false;
+                    if (j < cntT) {
+#ifdef VKR_SUN_STATS
+                        st_pre++;
+#endif
+                        const float4* tp = (const float4*)(tri_base + (size_t)(first + j) * 48u);
+                        const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
+                        const V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
+                        const V3 g = (e1 + e2) * (1.0f / 3.0f);                      // centroid - v0
+                        const V3 a1 = e1 - g, a2 = e2 - g;
+                        const float r2 = __builtin_fmaxf(dot3(g, g), __builtin_fmaxf(dot3(a1, a1), dot3(a2, a2)));
+                        const float r = __builtin_amdgcn_sqrtf(r2) * 1.001f;
+                        const V3 w = (v0 + g) - ro;
+                        const float h = dot3(w, cone_axis);
+                        const V3 wp = w - cone_axis * h;
+                        const float perp2 = dot3(wp, wp);
+                        const float lim = r + __builtin_fmaxf(h + r, 0.0f) * cone_tan +
+                                          (__builtin_fabsf(h) + __builtin_fabsf(wp.x) + __builtin_fabsf(wp.y) + __builtin_fabsf(wp.z)) * 1e-5f + 1e-7f;
+                        keep = !(perp2 > lim * lim);                                 // NaN keeps
+                    }
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) { const uint32_t ix = tq + mbcnt64(km); s_tq[ix] = first + j; s_tqp[ix] = (uint16_t)pix; }
+                    tq += (uint32_t)__popcll(km);
+                }
                 continue;
             }
             if (nq == 0u) break;
@@ -719,6 +793,9 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                 const uint32_t item = s_nq[nq + (uint32_t)lane];
                 pix = item >> KQ_NODE_BITS;
                 if ((s_mask[pix] & full) != full) {
+#ifdef VKR_SUN_STATS
+                    st_node++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) st_wnode++;
+#endif
                     const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
                     const float4* np = (const float4*)(node_base + ((size_t)node << 6));
                     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
@@ -785,6 +862,10 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
             }
         }
     }
+#ifdef VKR_SUN_STATS
+    atomicAdd(&sa.stats[0], st_pix); atomicAdd(&sa.stats[1], st_node); atomicAdd(&sa.stats[2], st_pre);
+    atomicAdd(&sa.stats[3], st_wnode); atomicAdd(&sa.stats[4], st_wtri); atomicAdd(&sa.stats[5], st_tri);
+#endif
 }
 
 static hipError_t shadow_q_launch(vkr_ctx* c, int mode, const ShadowArgs& sa, hipStream_t st)
@@ -816,7 +897,7 @@ hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const
 {
     if (count == 0) return hipSuccess;
     if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
-        ShadowArgs sa{wp, ng, valid, count, V3{L[0], L[1], L[2]}, radius, samples, V3{0, 0, 0}, out};
+        ShadowArgs sa{wp, ng, valid, count, V3{L[0], L[1], L[2]}, radius, samples, V3{0, 0, 0}, out, c->d_stats.p};
         if (c->sun_packets) {
             hipError_t e;
             if (!c->d_sun_frame.p && (e = c->d_sun_frame.alloc(sizeof(SunFrame))) != hipSuccess) return e;
@@ -847,7 +928,7 @@ hipError_t shadow_point_launch(vkr_ctx* c, const float* wp, const float* ng, con
 {
     if (count == 0) return hipSuccess;
     if (c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS)) {
-        ShadowArgs sa{wp, ng, valid, count, V3{0, 0, 1}, 0.0f, 1.0f, V3{P[0], P[1], P[2]}, out};
+        ShadowArgs sa{wp, ng, valid, count, V3{0, 0, 1}, 0.0f, 1.0f, V3{P[0], P[1], P[2]}, out, c->d_stats.p};
         return shadow_q_launch(c, 1, sa, st);
     }
     k_shadow_point<<<(count + VKR_TRACE_BLOCK - 1) / VKR_TRACE_BLOCK, VKR_TRACE_BLOCK, 0, st>>>(
