@@ -575,8 +575,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
 {
     extern __shared__ uint32_t smem[];
     const int rayCount = fp.rayCount;                                           // :252
-    uint32_t* s_tbest = smem;                                                   // [rayCount * 64] closest hit, float bits
-    uint32_t* s_nq = smem + (uint32_t)rayCount * 64u;                           // node items: ray << 22 | node
+    uint32_t* s_tbest = smem;                                                   // [rayCount * K1_TILE_PX] closest hit, float bits
+    uint32_t* s_nq = smem + (uint32_t)rayCount * (uint32_t)K1_TILE_PX;                           // node items: ray << 22 | node
     uint32_t* s_lq = s_nq + K1_NQ;                                              // leaf items: leaf reference ...
     uint16_t* s_lqr = (uint16_t*)(s_lq + KQ_LQ);                                // ... and its ray
     uint32_t* s_aq = (uint32_t*)(s_lqr + KQ_LQ);                                // MASK candidates: triangle index ...
@@ -875,7 +875,7 @@ hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* 
     hipError_t e;
     if (streaming) {
         // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
-        const size_t lds = (size_t)fp.rayCount * 64u * 4u + (size_t)K1_NQ * 4u + (size_t)KQ_LQ * 6u + (size_t)KQ_AQ * 6u;
+        const size_t lds = (size_t)fp.rayCount * (size_t)K1_TILE_PX * 4u + (size_t)K1_NQ * 4u + (size_t)KQ_LQ * 6u + (size_t)KQ_AQ * 6u;
         int per_cu = 0;
         if (c->stats_enabled) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<true>, K1_BLOCK, lds);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false>, K1_BLOCK, lds);
