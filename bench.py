@@ -408,6 +408,32 @@ def main():
                    "rays_per_frame": total_rays / K, "parallelism": f"rowband{n}" if n > 1 else "single"},
     }
 
+    if rank == 0 and not args.no_extra and n > 1:
+        # ---- untimed reference for the strong-scaling figure: the SAME frames, whole frame on this rank alone (the
+        # default N=1 run measures workload c3, so value(N)/value(1) across runs would compare different workloads)
+        rpass.band = None
+        rpass.reset()
+
+        def whole_frame(i):
+            rpass.gbuffer = gbs[i]
+            rpass.execute(PassExecuteContext(ubo=ubos[i]))
+            if shadows is not None:
+                shadows.gb = gbs[i]
+                shadows.sun(ubos[i])
+
+        whole_frame(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(Wu, Wu + K):
+            whole_frame(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t1
+        out["strong_scaling_reference"] = {
+            "n_gpus": 1, "ms_per_step": t1 / K * 1e3, "value": total_rays / t1 / 1e6, "unit": "Mrays/s",
+            "note": "same workload and frames, unsharded, on rank 0 alone after the timed region (other ranks idle); "
+                    "speed-up = value / this value"}
+        out["speedup_vs_one_gpu_same_workload"] = value / (total_rays / t1 / 1e6)
+
     if rank == 0 and not args.no_extra:
         # ---- per-kernel timing, HIP events on the launch stream, over the timed frames (single-GPU full frame)
         rpass.band = None
