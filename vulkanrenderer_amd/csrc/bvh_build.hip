@@ -414,8 +414,8 @@ __global__ __launch_bounds__(256) void k_sah_prep(BuildIn in, const uint32_t* pe
 
 // A: bin the triangles of every open range.  Every bin word is a count or a maximum (minima are stored complemented), so
 // lanes that fall into the same (range, bin) -- in Morton order that is most of a wave -- are first combined in the wave
-// and one lane issues the atomics.  Each block keeps LDS bins for the range of its first triangle; other ranges go to
-// the global bins directly.
+// and one lane issues the atomics.  Each wave takes 256 consecutive triangles and keeps LDS bins for the range of its
+// first one; other ranges go to the global bins directly.
 VKR_DI uint32_t wave_umax(uint32_t v)
 {
 #pragma unroll
@@ -427,16 +427,15 @@ __global__ __launch_bounds__(256) void k_sah_bin(uint32_t n, const uint32_t* tno
                                                  const uint32_t* level_count, uint32_t* bins)
 {
     if (*level_count == 0u) return;
-    __shared__ uint32_t s_bins[SAH_BIN_WORDS];
-    __shared__ uint32_t s_node;
-    const uint32_t base = blockIdx.x * (uint32_t)SAH_CHUNK;
-    if (threadIdx.x == 0) s_node = tnode[base];
-    for (int w = threadIdx.x; w < SAH_BIN_WORDS; w += 256) s_bins[w] = 0u;
+    __shared__ uint32_t s_all[4][SAH_BIN_WORDS];      // one set of bins per wave: the range of the wave's first triangle
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* s_bins = s_all[wave];
+    const uint32_t base = blockIdx.x * (uint32_t)SAH_CHUNK + (uint32_t)wave * (uint32_t)(SAH_CHUNK / 4);   // 256 consecutive triangles per wave
+    for (int w = lane; w < SAH_BIN_WORDS; w += 64) s_bins[w] = 0u;
+    const uint32_t mine = base < n ? tnode[base] : SAH_FINAL;    // wave-uniform
     __syncthreads();
-    const uint32_t mine = s_node;
-    const int lane = threadIdx.x & 63;
     for (int j = 0; j < SAH_CHUNK / 256; ++j) {
-        const uint32_t i = base + (uint32_t)j * 256u + threadIdx.x;
+        const uint32_t i = base + (uint32_t)j * 64u + (uint32_t)lane;
         uint32_t nd = i < n ? tnode[i] : SAH_FINAL;
         uint32_t v[SAH_WORDS - 1];
 #pragma unroll
@@ -498,7 +497,7 @@ __global__ __launch_bounds__(256) void k_sah_bin(uint32_t n, const uint32_t* tno
     }
     __syncthreads();
     if (mine != SAH_FINAL) {
-        for (int w = threadIdx.x; w < SAH_BIN_WORDS; w += 256) {
+        for (int w = lane; w < SAH_BIN_WORDS; w += 64) {
             const uint32_t v = s_bins[w];
             if (v) {
                 uint32_t* dst = bins + (size_t)mine * SAH_BIN_WORDS + w;
