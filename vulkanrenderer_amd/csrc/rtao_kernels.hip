@@ -735,63 +735,63 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
                     if (n > fit) n = fit ? fit : 1u;
                 }
                 nq -= n;
-                uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
-                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, ray = 0;
-                if ((uint32_t)lane < n) {
-                    const uint32_t item = s_nq[nq + (uint32_t)lane];
-                    ray = item >> KQ_NODE_BITS;
-                    const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
-                    const float4 a = slice[(size_t)ray * 3u], ir = slice[(size_t)ray * 3u + 2u];
-                    const float4* np = (const float4*)(node_base + ((size_t)node << 6));
-                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                    const float tb = u2f(s_tbest[ray]) * 1.000001f;   // padded: culling may only err towards extra visits
-                    if (STATS) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.wave_node_iters++; }
-                    V3 ro = V3{a.x, a.y, a.z};
-                    float tmin = a.w;
-                    if (round) {
-                        const float4 b = slice[(size_t)ray * 3u + 1u];
-                        const float adv = gmax(a.w * 2.0f, 2e-4f);
-                        ro = ro + V3{b.x, b.y, b.z} * adv;
-                        tmin = gmax(a.w, 1e-4f);
-                    }
-                    const V3 id = V3{ir.x, ir.y, ir.z};
-                    // Slab tests straight on the quantised planes (see k_trace): t = fma(q, s*id, (o - ro)*id)
-                    const uint32_t eb = f2u(q0.w);
-                    const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
-                                az = u2f(((eb >> 16) & 0xffu) << 23) * id.z;
-                    const float bx = (q0.x - ro.x) * id.x, by = (q0.y - ro.y) * id.y, bz = (q0.z - ro.z) * id.z;
-                    const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
-                    const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
-                    const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
-                    r0 = f2u(q3.x); r1 = f2u(q3.y); r2 = f2u(q3.z); r3 = f2u(q3.w);
-                    // two children per packed fma (v_pk_fma_f32 rounds each half like the scalar fma)
+                // Every lane runs the step; lanes without an item work on item 0 (ray 0 at the root: valid addresses, no
+                // side effects) and are masked out of the hit tests.  Keeping the step in one basic block lets the hit /
+                // leaf ballots come straight out of the compares (v_cmp -> SGPR pair) instead of being re-materialised
+                // from booleans carried across a divergent region: -16 VALU instructions per step.
+                const bool act = (uint32_t)lane < n;
+                const uint32_t item = act ? s_nq[nq + (uint32_t)lane] : 0u;
+                const uint32_t ray = item >> KQ_NODE_BITS;
+                const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
+                const float4 a = slice[(size_t)ray * 3u], ir = slice[(size_t)ray * 3u + 2u];
+                const float4* np = (const float4*)(node_base + ((size_t)node << 6));
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                // padded: culling may only err towards extra visits; lanes without an item get an exit distance below any
+                // entry distance (tn >= tmin > 0), so none of their four tests can pass
+                const float tb = act ? u2f(s_tbest[ray]) * 1.000001f : -3.0e38f;
+                if (STATS) { if (act) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.wave_node_iters++; } }
+                V3 ro = V3{a.x, a.y, a.z};
+                float tmin = a.w;
+                if (round) {
+                    const float4 b = slice[(size_t)ray * 3u + 1u];
+                    const float adv = gmax(a.w * 2.0f, 2e-4f);
+                    ro = ro + V3{b.x, b.y, b.z} * adv;
+                    tmin = gmax(a.w, 1e-4f);
+                }
+                const V3 id = V3{ir.x, ir.y, ir.z};
+                // Slab tests straight on the quantised planes (see k_trace): t = fma(q, s*id, (o - ro)*id)
+                const uint32_t eb = f2u(q0.w);
+                const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
+                            az = u2f(((eb >> 16) & 0xffu) << 23) * id.z;
+                const float bx = (q0.x - ro.x) * id.x, by = (q0.y - ro.y) * id.y, bz = (q0.z - ro.z) * id.z;
+                const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
+                const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
+                const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
+                const uint32_t r0 = f2u(q3.x), r1 = f2u(q3.y), r2 = f2u(q3.z), r3 = f2u(q3.w);
+                // two children per packed fma (v_pk_fma_f32 rounds each half like the scalar fma)
 #define VKR_PLANES(W, A, B, P01, P23)                                                                               \
     const f2v P01 = pk_fma(f2v{ubyte_f(W, 0), ubyte_f(W, 1)}, A, B), P23 = pk_fma(f2v{ubyte_f(W, 2), ubyte_f(W, 3)}, A, B);
-                    VKR_PLANES(nx4, ax, bx, nx01, nx23) VKR_PLANES(ny4, ay, by, ny01, ny23) VKR_PLANES(nz4, az, bz, nz01, nz23)
-                    VKR_PLANES(fx4, ax, bx, fx01, fx23) VKR_PLANES(fy4, ay, by, fy01, fy23) VKR_PLANES(fz4, az, bz, fz01, fz23)
+                VKR_PLANES(nx4, ax, bx, nx01, nx23) VKR_PLANES(ny4, ay, by, ny01, ny23) VKR_PLANES(nz4, az, bz, nz01, nz23)
+                VKR_PLANES(fx4, ax, bx, fx01, fx23) VKR_PLANES(fy4, ay, by, fy01, fy23) VKR_PLANES(fz4, az, bz, fz01, fz23)
 #undef VKR_PLANES
-#define VKR_SLABQ(HC, NX, NY, NZ, FX, FY, FZ)                                                                       \
-    {                                                                                                               \
-        float tn = __builtin_fmaxf(__builtin_fmaxf(NX, NY), __builtin_fmaxf(NZ, tmin));                             \
-        float tf = __builtin_fminf(__builtin_fminf(FX, FY), __builtin_fminf(FZ, tb));                               \
-        HC = (tn <= tf) ? f2u(tn) : 0xffffffffu;                                                                    \
-    }
-                    VKR_SLABQ(k0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)
-                    VKR_SLABQ(k1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)
-                    VKR_SLABQ(k2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)
-                    VKR_SLABQ(k3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
+                // a NaN entry distance fails the comparison, like the k != 0xffffffff test of the keyed form did
+#define VKR_SLABQ(H, NX, NY, NZ, FX, FY, FZ)                                                                        \
+    const bool H = __builtin_fmaxf(__builtin_fmaxf(NX, NY), __builtin_fmaxf(NZ, tmin)) <=                           \
+                   __builtin_fminf(__builtin_fminf(FX, FY), __builtin_fminf(FZ, tb));
+                VKR_SLABQ(h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)
+                VKR_SLABQ(h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)
+                VKR_SLABQ(h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)
+                VKR_SLABQ(h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
 #undef VKR_SLABQ
-                }
-                const bool h0 = k0 != 0xffffffffu, h1 = k1 != 0xffffffffu, h2 = k2 != 0xffffffffu, h3 = k3 != 0xffffffffu;
                 // append the hit children: internal nodes to the node queue, leaves to the leaf queue, slot by slot
                 // (measured: sorting them near-to-far first saves 1 % of the visits and costs more than that; one
                 // lane-major prefix sum instead of per-slot ballots makes a ray's siblings pop together and costs 9 %)
 #define VKR_APPEND(HC, RC)                                                                                          \
     {                                                                                                               \
-        const bool isl = (int)RC < 0;                                                                               \
-        const unsigned long long mn = __ballot(HC && !isl), ml = __ballot(HC && isl);                               \
+        const unsigned long long hm = __ballot(HC), lm = __ballot((int)RC < 0);                                     \
+        const unsigned long long mn = hm & ~lm, ml = hm & lm;                                                       \
         if (HC) {                                                                                                   \
-            if (isl) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqr[ix] = (uint16_t)ray; }            \
+            if ((int)RC < 0) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqr[ix] = (uint16_t)ray; }    \
             else s_nq[nq + mbcnt64(mn)] = (ray << KQ_NODE_BITS) | RC;                                               \
         }                                                                                                           \
         nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
