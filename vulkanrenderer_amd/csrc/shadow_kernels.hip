@@ -787,28 +787,29 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                 if (n > fit) n = fit ? fit : 1u;
             }
             nq -= n;
-            bool h0 = false, h1 = false, h2 = false, h3 = false;
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, pix = 0;
-            if ((uint32_t)lane < n) {
-                const uint32_t item = s_nq[nq + (uint32_t)lane];
-                pix = item >> KQ_NODE_BITS;
-                if ((s_mask[pix] & full) != full) {
+            // one basic block (see k_trace_q): lanes without an item, or whose pixel is already fully occluded, run on
+            // their (or item 0's) addresses with an exit distance that fails every test
+            const bool act = (uint32_t)lane < n;
+            const uint32_t item = act ? s_nq[nq + (uint32_t)lane] : 0u;
+            const uint32_t pix = item >> KQ_NODE_BITS;
+            const bool live = act && (s_mask[pix] & full) != full;
 #ifdef VKR_SUN_STATS
-                    st_node++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) st_wnode++;
+            if (live) { st_node++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) st_wnode++; }
 #endif
-                    const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
-                    const float4* np = (const float4*)(node_base + ((size_t)node << 6));
-                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                    const float4 o = s_org[pix];
-                    const uint32_t eb = f2u(q0.w);
-                    const float sx = u2f((eb & 0xffu) << 23), sy = u2f(((eb >> 8) & 0xffu) << 23), sz = u2f(((eb >> 16) & 0xffu) << 23);
-                    // plane - origin per axis: fma(q, s, node origin - ray origin)
-                    const float bx = q0.x - o.x, by = q0.y - o.y, bz = q0.z - o.z;
-                    const uint32_t nx4 = posx ? f2u(q1.x) : f2u(q1.w), fx4 = posx ? f2u(q1.w) : f2u(q1.x);
-                    const uint32_t ny4 = posy ? f2u(q1.y) : f2u(q2.x), fy4 = posy ? f2u(q2.x) : f2u(q1.y);
-                    const uint32_t nz4 = posz ? f2u(q1.z) : f2u(q2.y), fz4 = posz ? f2u(q2.y) : f2u(q1.z);
-                    r0 = f2u(q3.x); r1 = f2u(q3.y); r2 = f2u(q3.z); r3 = f2u(q3.w);
-                    // entry: the smallest near-plane distance any direction can have; exit: the largest far-plane one
+            const float tbx = live ? tb : -3.0e38f;
+            const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
+            const float4* np = (const float4*)(node_base + ((size_t)node << 6));
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            const float4 o = s_org[pix];
+            const uint32_t eb = f2u(q0.w);
+            const float sx = u2f((eb & 0xffu) << 23), sy = u2f(((eb >> 8) & 0xffu) << 23), sz = u2f(((eb >> 16) & 0xffu) << 23);
+            // plane - origin per axis: fma(q, s, node origin - ray origin)
+            const float bx = q0.x - o.x, by = q0.y - o.y, bz = q0.z - o.z;
+            const uint32_t nx4 = posx ? f2u(q1.x) : f2u(q1.w), fx4 = posx ? f2u(q1.w) : f2u(q1.x);
+            const uint32_t ny4 = posy ? f2u(q1.y) : f2u(q2.x), fy4 = posy ? f2u(q2.x) : f2u(q1.y);
+            const uint32_t nz4 = posz ? f2u(q1.z) : f2u(q2.y), fz4 = posz ? f2u(q2.y) : f2u(q1.z);
+            const uint32_t r0 = f2u(q3.x), r1 = f2u(q3.y), r2 = f2u(q3.z), r3 = f2u(q3.w);
+            // entry: the smallest near-plane distance any direction can have; exit: the largest far-plane one
 #define VKR_PKT_AXIS(OK, NQW, FQW, C, S, B, IL, IH, TN, TF)                                                         \
     if (OK) {                                                                                                       \
         const float an = fma_(ubyte_f(NQW, C), S, B), af = fma_(ubyte_f(FQW, C), S, B);                             \
@@ -817,31 +818,28 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
     } else {                                                                                                        \
         /* directions straddle zero on this axis: only "origin outside the slab on both sides" could cull */       \
     }
-#define VKR_PKT_SLAB(HC, C)                                                                                         \
+            // unused slots are stored inverted (near plane beyond far plane) and fail on any constrained axis; with all
+            // three axes unconstrained nothing could cull them, so they are masked explicitly
+#define VKR_PKT_SLAB(HC, C, RC)                                                                                     \
+    bool HC;                                                                                                        \
     {                                                                                                               \
         float tn = -3.0e38f, tf = 3.0e38f;                                                                          \
         VKR_PKT_AXIS(okx, nx4, fx4, C, sx, bx, ilx, ihx, tn, tf)                                                    \
         VKR_PKT_AXIS(oky, ny4, fy4, C, sy, by, ily, ihy, tn, tf)                                                    \
         VKR_PKT_AXIS(okz, nz4, fz4, C, sz, bz, ilz, ihz, tn, tf)                                                    \
         tn = __builtin_fmaxf(tn - __builtin_fabsf(tn) * 1e-6f, tmin);                                               \
-        tf = __builtin_fminf(tf + __builtin_fabsf(tf) * 1e-6f, tb);                                                 \
-        HC = (tn <= tf);                                                             \
+        tf = __builtin_fminf(tf + __builtin_fabsf(tf) * 1e-6f, tbx);                                                \
+        HC = (tn <= tf) && (RC != VKR_CHILD_NONE);                                                                  \
     }
-                    VKR_PKT_SLAB(h0, 0) VKR_PKT_SLAB(h1, 1) VKR_PKT_SLAB(h2, 2) VKR_PKT_SLAB(h3, 3)
+            VKR_PKT_SLAB(h0, 0, r0) VKR_PKT_SLAB(h1, 1, r1) VKR_PKT_SLAB(h2, 2, r2) VKR_PKT_SLAB(h3, 3, r3)
 #undef VKR_PKT_SLAB
 #undef VKR_PKT_AXIS
-                    // unused slots are stored inverted (near plane beyond far plane) and fail on any constrained
-                    // axis; with all three axes unconstrained nothing could cull them, so mask them explicitly
-                    h0 = h0 && r0 != VKR_CHILD_NONE; h1 = h1 && r1 != VKR_CHILD_NONE;
-                    h2 = h2 && r2 != VKR_CHILD_NONE; h3 = h3 && r3 != VKR_CHILD_NONE;
-                }
-            }
 #define VKR_APPEND(HC, RC)                                                                                          \
     {                                                                                                               \
-        const bool isl = (int)RC < 0;                                                                               \
-        const unsigned long long mn = __ballot(HC && !isl), ml = __ballot(HC && isl);                               \
+        const unsigned long long hm = __ballot(HC), lm = __ballot((int)RC < 0);                                     \
+        const unsigned long long mn = hm & ~lm, ml = hm & lm;                                                       \
         if (HC) {                                                                                                   \
-            if (isl) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqp[ix] = (uint16_t)pix; }            \
+            if ((int)RC < 0) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqp[ix] = (uint16_t)pix; }    \
             else s_nq[nq + mbcnt64(mn)] = (pix << KQ_NODE_BITS) | RC;                                               \
         }                                                                                                           \
         nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
