@@ -330,24 +330,46 @@ def main():
             work.wait()
             bands.unpack_frame(gathered, planes, H, n)
 
+    # The sun-shadow kernel shares nothing with the RTAO kernels (vkr_rt.h), so it is issued on a second stream right after
+    # K1: its persistent waves fill the CUs as K1's waves drain, instead of the two launches each paying its own tail.
+    side = torch.cuda.Stream(device=dev) if (shadows is not None and os.environ.get("VKR_BENCH_SUN_STREAM", "1") == "1") else None
+    ev_sun, ev_sun_read = torch.cuda.Event(), torch.cuda.Event()
+
+    def issue_sun(i, rows):
+        shadows.gb = gbs[i]
+        if side is None:
+            shadows.sun(ubos[i], rows=rows)
+            return
+        side.wait_event(ev_sun_read)          # the previous frame's reader of sun_vis (recorded on the main stream) is done
+        with torch.cuda.stream(side):
+            shadows.sun(ubos[i], rows=rows)
+            ev_sun.record(side)
+
+    def join_sun():
+        if side is not None:
+            torch.cuda.current_stream().wait_event(ev_sun)
+
     def step(i):
         rpass.gbuffer = gbs[i]
         if n == 1:
             rpass.execute(PassExecuteContext(ubo=ubos[i]))
             if shadows is not None:
-                shadows.gb = gbs[i]
-                shadows.sun(ubos[i])
+                issue_sun(i, None)                                             # queued behind K1: K1 holds the CUs until it drains
+                join_sun()
+                ev_sun_read.record(torch.cuda.current_stream())
             return
         rpass.traceStripes(ubos[i], rank, n)                                  # overlaps the previous frame's output gather
+        if shadows is not None:
+            issue_sun(i, (y0, y1))                                             # fills K1's drain, then overlaps the history gather
         hc = rpass.historyCurr()
         plan.pack(hc, rank, hist_send)
-        work = bands.all_gather_bytes(hist_send, hist_recv, async_op=True)     # overlaps the sun-shadow kernel below
+        work = bands.all_gather_bytes(hist_send, hist_recv, async_op=True)
         finish_output_gather()                                                 # frame i-1 is assembled before its planes are rewritten
         planes = [rpass.rtao_full]
         if shadows is not None:
-            shadows.gb = gbs[i]
-            shadows.sun(ubos[i], rows=(y0, y1))
+            join_sun()
             sun16[y0:y1].copy_(shadows.sun_vis[y0:y1])
+            ev_sun_read.record(torch.cuda.current_stream())
             planes.append(sun16.view(torch.int16))
         work.wait()
         plan.unpack(hist_recv, hc)

@@ -259,7 +259,10 @@ VKR_API int vkr_rtao_image(vkr_ctx* ctx, uint32_t which, uint16_t** out);
 
 /* Replaces: ComputeShadowVisibilityDirectional (pbr.frag:217-260) with L = -normalize(directionalLightDir.xyz)
  * (pbr.frag:379-380) taken from `light_dir_to_light` (already negated+normalised by the caller),
- * sun_radius / samples = directionalLightParams.xy. */
+ * sun_radius / samples = directionalLightParams.xy.
+ * Concurrency: this call shares no scratch with the vkr_rtao_* calls, so it may be issued on a second stream while an
+ * RTAO frame of the same context runs (its persistent waves then fill the drain of the trace kernel).  No other two
+ * calls on one context may overlap. */
 VKR_API int vkr_shadow_sun(vkr_ctx* ctx, const float* world_pos, const float* geom_normal, const uint8_t* valid,
                            uint32_t pixel_count, const float light_dir_to_light[3], float sun_radius,
                            float sample_count, float* out_vis, void* stream);

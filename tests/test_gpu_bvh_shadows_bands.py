@@ -452,6 +452,44 @@ def test_sun_shadows_small_launch_chunks(torch_mod, oracle_mod):
     ctx.close()
 
 
+def test_sun_shadows_overlap_an_rtao_frame_on_a_second_stream(torch_mod):
+    """vkr_shadow_sun shares no scratch with the vkr_rtao_* calls (own chunk counter): issued on a second stream while an
+    RTAO frame of the same context runs, both produce the bits of the sequential calls -- at a size where both kernels
+    run many persistent waves for a while (sponza-class, 1280x720), several frames in a row."""
+    import torch
+    from vulkanrenderer_amd import FrameState, make_sponza_class
+    from vulkanrenderer_amd.renderer import GBuffer, PassExecuteContext, RtaoComputePass, ShadowRays, generate_gbuffer
+    scene = make_sponza_class()
+    W, H = 1280, 720
+    ctx, rt, gb0 = _ctx(scene, W, H)
+    gb = GBuffer(ctx, with_shading_inputs=True)
+    fs = FrameState(W, H, ray_count=8, sun_samples=16)
+    eye, tgt = scene.cameras[0]
+    ubos = [fs.update((eye[0] + 0.05 * f, eye[1], eye[2]), tgt) for f in range(3)]
+    generate_gbuffer(ctx, ubos[0], gb)
+    ctx.sync()
+    sh = ShadowRays(ctx, gb)
+    rp = RtaoComputePass(ctx, gb, atrous_iterations=2)
+    want = []
+    for ubo in ubos:                                   # sequential reference: one stream
+        rp.execute(PassExecuteContext(ubo=ubo))
+        sun = sh.sun(ubo).clone()
+        ctx.sync()
+        want.append((to_np_u16(rp.rtao_full).copy(), sun.cpu().numpy()))
+    rp.reset()
+    side, ev = torch.cuda.Stream(), torch.cuda.Event()
+    for k, ubo in enumerate(ubos):                     # overlapped: sun on the second stream, queued right behind K1
+        rp.execute(PassExecuteContext(ubo=ubo))
+        with torch.cuda.stream(side):
+            sh.sun(ubo)
+            ev.record(side)
+        torch.cuda.current_stream().wait_event(ev)
+        ctx.sync()
+        assert to_np_u16(rp.rtao_full).tobytes() == want[k][0].tobytes(), k
+        assert sh.sun_vis.cpu().numpy().tobytes() == want[k][1].tobytes(), k
+    ctx.close()
+
+
 def test_full_size_properties_1080p(torch_mod):
     """At BASELINE size without the oracle: AO in [0,1], sky pixels exactly 1, a static camera converges
     (|frame k+1 - frame k| shrinks), ray counters consistent with the valid-pixel count."""

@@ -909,9 +909,10 @@ hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const
             while (pix > 64u && (count + pix - 1u) / pix < 4u * blocks) pix >>= 1;
             const uint32_t n_chunks = (count + pix - 1u) / pix;
             if (blocks > n_chunks) blocks = n_chunks;
-            if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(8)) != hipSuccess) return e;
-            if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
-            k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, c->d_tile_counter.p);
+            // its own chunk counter (and d_sun_frame): this launch may overlap vkr_rtao_* launches of another stream
+            if (!c->d_sun_counter.p && (e = c->d_sun_counter.alloc(8)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(c->d_sun_counter.p, 0, 4, st)) != hipSuccess) return e;
+            k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, c->d_sun_counter.p);
             return hipGetLastError();
         }
         return shadow_q_launch(c, 0, sa, st);
