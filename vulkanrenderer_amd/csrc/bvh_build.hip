@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_emit_sorted(BuildIn in, const uint32_t*
 #define VKR_TL_MAX 1024
 #endif
 #ifndef VKR_TL_R
-#define VKR_TL_R 8
+#define VKR_TL_R 16
 #endif
 constexpr int TL_MAX = VKR_TL_MAX;     // triangles per treelet = threads per block (64 .. 1024)
 constexpr int TL_MIN = 4;
