@@ -92,7 +92,7 @@ def cpu_baseline(scene, wl, ubos, gb0_depth, gb0_normal, target_seconds):
     t1 = time.perf_counter()
     O.atrous(ubos[0], 1, cur, gb0_depth, gb0_normal, ymid, ymid + rows)
     dta = time.perf_counter() - t1
-    return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return (ymid, ymid + rows, cur), {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"oracle K1 trace+temporal on rows [{ymid},{ymid + rows}) of frame 0 at {W}x{H}, {rays} rays/px "
                       f"({st['rays']} rays in {dt:.2f} s; CPU BVH build {build_s:.1f} s not counted); "
                       f"one A-Trous iteration on the same rows {dta * 1e3:.0f} ms"}
@@ -517,7 +517,21 @@ def main():
     if rank == 0 and n == 1 and args.cpu_seconds > 0:
         depth0 = gbs[Wu].linear_depth.cpu().numpy().view(np.uint16)
         normal0 = gbs[Wu].normal.cpu().numpy().view(np.uint16)
-        out["cpu_baseline"] = cpu_baseline(scene, wl, [ubos[Wu]], depth0, normal0, args.cpu_seconds)
+        (ya, yb, want), out["cpu_baseline"] = cpu_baseline(scene, wl, [ubos[Wu]], depth0, normal0, args.cpu_seconds)
+        # the oracle is the checker here too: the GPU's trace+temporal output for the same frame, from the same cleared
+        # history, against the rows the CPU leg just computed (the parity tests proper are tests/ -m gpu)
+        rpass.band = None
+        rpass.reset()
+        rpass.gbuffer = gbs[Wu]
+        rpass.dispatchTrace(ubos[Wu])
+        ctx.sync()
+        got = rpass.image(0).cpu().numpy().view(np.uint16).reshape(H, W)[ya:yb]
+        ref = np.asarray(want).view(np.uint16).reshape(H, W)[ya:yb]
+        diff = np.abs(got.view(np.float16).astype(np.float32) - ref.view(np.float16).astype(np.float32))
+        out["parity"] = {"checked": f"K1 trace+temporal, rows [{ya},{yb}) of the first timed frame, GPU vs CPU oracle (R16F bits)",
+                         "pixels": int(got.size), "mismatching_pixels": int((got != ref).sum()),
+                         "pixels_over_1_255": int((diff > 1.0 / 255.0).sum()), "max_abs_diff": float(diff.max())}
+        rpass.endFrame()
 
     if rank == 0:
         print(json.dumps(out))
