@@ -10,6 +10,8 @@
 #include <cstring>
 #include <random>
 #include <vector>
+#include <array>
+#include <functional>
 struct V3 { float x, y, z; };
 static V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 static V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -249,6 +251,45 @@ static Wide collapse(const Tree& t)
         W.w[wi] = wn; }
     return W;
 }
+// SAH-optimal 4-ary collapse by dynamic programming over the binary tree (Ylitie, Karras, Laine 2017, for width 4):
+// D[n][j] = cheapest way to represent subtree n as at most j+1 roots (wide nodes or leaves).
+static float CT = 0.6f;   // cost of a triangle test relative to a node step
+static Wide collapse_dp(const Tree& t)
+{
+    const int N = (int)t.n.size();
+    std::vector<std::array<float, 4>> D(N); std::vector<std::array<signed char, 4>> split(N);   // split[n][j]: roots given to the left child (0 = keep n as one root)
+    std::vector<float> cint(N, 1e30f); std::vector<signed char> isplit(N, 0), isleaf(N, 0);
+    // post-order
+    std::vector<int> order; order.reserve(N); { std::vector<int> st{t.root}; while (!st.empty()) { int n = st.back(); st.pop_back(); order.push_back(n); if (t.n[n].l >= 0) { st.push_back(t.n[n].l); st.push_back(t.n[n].r); } } }
+    for (int oi = N - 1; oi >= 0; --oi) { int n = order[oi]; const BNode& b = t.n[n]; float A = b.box.area();
+        float cleaf = b.count <= LEAFMAX ? A * CT * b.count : 1e30f;
+        if (b.l < 0) { for (int j = 0; j < 4; ++j) { D[n][j] = A * CT * b.count; split[n][j] = 0; } isleaf[n] = 1; continue; }
+        int l = b.l, r = b.r;
+        float best = 1e30f; int bi = 1;
+        for (int i = 1; i <= 3; ++i) { float c = D[l][i - 1] + D[r][4 - i - 1]; if (c < best) { best = c; bi = i; } }
+        cint[n] = A + best; isplit[n] = (signed char)bi;
+        float c1 = std::min(cleaf, cint[n]); isleaf[n] = cleaf <= cint[n];
+        D[n][0] = c1; split[n][0] = 0;
+        for (int j = 1; j < 4; ++j) { float bestj = D[n][j - 1]; int bs = split[n][j - 1] ? split[n][j - 1] : 0; bool own = true;
+            for (int i = 1; i <= j; ++i) { float c = D[l][i - 1] + D[r][j + 1 - i - 1]; if (c < bestj) { bestj = c; bs = i; own = false; } }
+            D[n][j] = bestj; split[n][j] = own ? split[n][j - 1] : (signed char)bs; }
+    }
+    // materialise
+    Wide W; W.t = &t; std::vector<int> bin{t.root}; W.w.emplace_back();
+    // gather roots of subtree n when allowed j+1 roots
+    std::function<void(int, int, std::vector<int>&)> roots = [&](int n, int j, std::vector<int>& out) {
+        int sp = split[n][j]; if (sp == 0 || t.n[n].l < 0) { out.push_back(n); return; }
+        roots(t.n[n].l, sp - 1, out); roots(t.n[n].r, j + 1 - sp - 1, out); };
+    for (size_t wi = 0; wi < bin.size(); ++wi) { int b = bin[wi]; std::vector<int> ch;
+        if (t.n[b].l < 0 || (isleaf[b] && t.n[b].count <= LEAFMAX)) ch = {b};
+        else { int sp = isplit[b]; roots(t.n[b].l, sp - 1, ch); roots(t.n[b].r, 4 - sp - 1, ch); }
+        WNode wn; wn.nch = (int)ch.size();
+        for (int c = 0; c < wn.nch; ++c) { wn.cb[c] = t.n[ch[c]].box;
+            if (t.n[ch[c]].l < 0 || (isleaf[ch[c]] && t.n[ch[c]].count <= LEAFMAX)) wn.ref[c] = ~ch[c];
+            else { wn.ref[c] = (int)bin.size(); bin.push_back(ch[c]); W.w.emplace_back(); } }
+        W.w[wi] = wn; }
+    return W;
+}
 static bool slab(const Box& b, V3 o, V3 inv, float tmin, float tmax)
 {
     float t0 = (b.lo.x - o.x) * inv.x, t1 = (b.hi.x - o.x) * inv.x; if (t0 > t1) std::swap(t0, t1); tmin = std::max(tmin, t0); tmax = std::min(tmax, t1);
@@ -285,7 +326,9 @@ int main(int argc, char** argv)
         ro[i] = p + nn * 1e-3f; rd[i] = dd; }
     float radius = argc > 2 ? atof(argv[2]) : 1.2f;
     if (argc > 3) LEAFMAX = atoi(argv[3]);
-    auto eval = [&](const char* name, const Tree& t) { Wide W = collapse(t); uint64_t nv = 0, tt = 0; for (int i = 0; i < NR; ++i) trace(W, ro[i], rd[i], radius, nv, tt);
+    auto eval = [&](const char* name, const Tree& t) { if (getenv("DP")) { CT = atof(getenv("DP")); Wide W = collapse_dp(t); uint64_t nv = 0, tt = 0; for (int i = 0; i < NR; ++i) trace(W, ro[i], rd[i], radius, nv, tt);
+        printf("%-10s DP collapse (ct %.2f): wide nodes %zu  nodes/ray %.2f  tris/ray %.2f\n", name, CT, W.w.size(), (double)nv / NR, (double)tt / NR); fflush(stdout); }
+        Wide W = collapse(t); uint64_t nv = 0, tt = 0; for (int i = 0; i < NR; ++i) trace(W, ro[i], rd[i], radius, nv, tt);
         printf("%-10s binary SAH %.1f  wide nodes %zu  nodes/ray %.2f  tris/ray %.2f\n", name, sah_cost(t), W.w.size(), (double)nv / NR, (double)tt / NR); fflush(stdout); };
     bool all = argc > 4;
     if (all) {
