@@ -63,6 +63,25 @@ def test_ibl_compute_bit_exact_small(ctx, sky):
     assert np.allclose(m0[4, 9, 5, :3], oracle.ibl_sample_cube(cube_np, d), rtol=2e-3)
 
 
+def test_direct_cube_sampling_path_matches_the_footprint_table(sky, monkeypatch):
+    """The convolution kernels sample a footprint table built from the cube (one 64-byte record per bilinear footprint,
+    seams and corners resolved once); cubes above 2048^2 -- and VKR_IBL_QUADS=0 -- sample the image directly.  Both
+    paths must give the oracle's bits, on a cube small enough (8^2) that seam and corner footprints are frequent."""
+    from vulkanrenderer_amd import Context, EquirectToCubemap, IblPrecompute
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VKR_IBL_QUADS", flag)
+        c = Context(32, 32)
+        cube = EquirectToCubemap.convert(c, torch.from_numpy(sky).to(c.device), 8)
+        res = IblPrecompute.compute(c, cube, irradiance_size=4, prefilter_size=8, brdf_lut_size=16)
+        outs.append((cube.cpu().numpy(), to_np16(res.irradiance).copy(), to_np16(res.prefilter).copy()))
+        c.close()
+    cube_np = outs[0][0]
+    for _, irr, pre in outs:
+        assert irr.tobytes() == oracle.ibl_irradiance(cube_np, 4, 1).tobytes()
+        assert pre.tobytes() == oracle.ibl_prefilter(cube_np, 8, 1).tobytes()
+
+
 def test_constant_environment_on_gpu(ctx):
     from vulkanrenderer_amd import IblPrecompute
     cube = torch.ones((6, 8, 8, 4), dtype=torch.float32, device=ctx.device)

@@ -110,20 +110,10 @@ VKR_DI size_t across_edge(int S, int f, int i, int j)
     return ((size_t)g * S + jo) * S + io;
 }
 
-// samplerCube, LINEAR, one mip, seamless
-VKR_DI V3 cube_sample(const float4* cube, int S, V3 r)
+// the four texels of the bilinear footprint [i0, i0+1] x [j0, j0+1] of face f (i0, j0 in [-1, S-1]): seamless -- texels
+// beyond an edge come from the neighbouring face, the missing one at a cube corner is the mean of the other three
+VKR_DI void cube_footprint(const float4* cube, int S, int f, int i0, int j0, float4 v[4])
 {
-    const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
-    float sc, tc, ma;
-    int f;
-    if (az >= ay && az >= ax) { f = r.z < 0.0f ? 5 : 4; sc = r.z < 0.0f ? -r.x : r.x; tc = -r.y; ma = az; }
-    else if (ay >= ax) { f = r.y < 0.0f ? 3 : 2; sc = r.x; tc = r.y < 0.0f ? -r.z : r.z; ma = ay; }
-    else { f = r.x < 0.0f ? 1 : 0; sc = r.x < 0.0f ? r.z : -r.z; tc = -r.y; ma = ax; }
-    const float s = 0.5f * (sc / ma) + 0.5f, t = 0.5f * (tc / ma) + 0.5f;
-    const float x = s * (float)S - 0.5f, y = t * (float)S - 0.5f;
-    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y), wx = x - fx, wy = y - fy;
-    const int i0 = (int)fx, j0 = (int)fy;
-    float4 v[4];
     int missing = -1;
     if (i0 >= 0 && j0 >= 0 && i0 + 1 < S && j0 + 1 < S) {       // interior: the common case
         const float4* p = cube + ((size_t)f * S + j0) * S + i0;
@@ -149,11 +139,51 @@ VKR_DI V3 cube_sample(const float4* cube, int S, V3 r)
                 if (k == missing) v[k] = m;
         }
     }
+}
+
+// samplerCube, LINEAR, one mip, seamless.  QUADS: `cube` is the footprint table of k_ibl_quads (one aligned 64-byte record
+// per footprint: the scattered samples of the convolutions then touch ONE cache line instead of two rows of the image,
+// and the edge / corner cases are resolved once per footprint instead of once per sample); same texels, same arithmetic.
+template <bool QUADS>
+VKR_DI V3 cube_sample(const float4* cube, int S, V3 r)
+{
+    const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
+    float sc, tc, ma;
+    int f;
+    if (az >= ay && az >= ax) { f = r.z < 0.0f ? 5 : 4; sc = r.z < 0.0f ? -r.x : r.x; tc = -r.y; ma = az; }
+    else if (ay >= ax) { f = r.y < 0.0f ? 3 : 2; sc = r.x; tc = r.y < 0.0f ? -r.z : r.z; ma = ay; }
+    else { f = r.x < 0.0f ? 1 : 0; sc = r.x < 0.0f ? r.z : -r.z; tc = -r.y; ma = ax; }
+    const float s = 0.5f * (sc / ma) + 0.5f, t = 0.5f * (tc / ma) + 0.5f;
+    const float x = s * (float)S - 0.5f, y = t * (float)S - 0.5f;
+    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y), wx = x - fx, wy = y - fy;
+    const int i0 = (int)fx, j0 = (int)fy;
+    float4 v[4];
+    if (QUADS) {
+        // |sc|, |tc| <= ma, so x, y lie in [-0.5, S - 0.5] and i0, j0 in [-1, S-1]; clamped all the same (NaN directions)
+        const int ii = iclamp(i0 + 1, 0, S), jj = iclamp(j0 + 1, 0, S);
+        const float4* q = cube + (((size_t)f * (size_t)(S + 1) + (size_t)jj) * (size_t)(S + 1) + (size_t)ii) * 4u;
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    } else {
+        cube_footprint(cube, S, f, i0, j0, v);
+    }
     V3 o;
     { const float top = v[0].x + wx * (v[1].x - v[0].x), bot = v[2].x + wx * (v[3].x - v[2].x); o.x = top + wy * (bot - top); }
     { const float top = v[0].y + wx * (v[1].y - v[0].y), bot = v[2].y + wx * (v[3].y - v[2].y); o.y = top + wy * (bot - top); }
     { const float top = v[0].z + wx * (v[1].z - v[0].z), bot = v[2].z + wx * (v[3].z - v[2].z); o.z = top + wy * (bot - top); }
     return o;
+}
+
+// footprint table: record ((f * (S+1) + j0+1) * (S+1) + i0+1) = the four texels cube_footprint(f, i0, j0) returns
+__global__ __launch_bounds__(256) void k_ibl_quads(const float4* cube, int S, float4* quads)
+{
+    const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const size_t per = (size_t)(S + 1) * (size_t)(S + 1);
+    if (t >= 6u * per) return;
+    const int f = (int)(t / per), jj = (int)((t % per) / (size_t)(S + 1)), ii = (int)(t % (size_t)(S + 1));
+    float4 v[4];
+    cube_footprint(cube, S, f, ii - 1, jj - 1, v);
+    float4* q = quads + t * 4u;
+    q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
 }
 
 // ---------------------------------------------------------------- equirect_to_cubemap.frag
@@ -197,6 +227,7 @@ __global__ void k_ibl_irr_tables(float2* tables, int nphi, int ntheta)
 }
 
 // one block per output texel; thread p owns the phi row p (sequential over theta), rows are added in order
+template <bool QUADS>
 __global__ __launch_bounds__(256) void k_ibl_irradiance(const float4* cube, int S, const float2* tables, int nphi, int ntheta,
                                                         uint16_t* out, int So)
 {
@@ -218,7 +249,7 @@ __global__ __launch_bounds__(256) void k_ibl_irradiance(const float4* cube, int 
             const float st = s_theta[t].x, ct = s_theta[t].y;
             const float tx = st * ph.y, ty = st * ph.x, tz = ct;                 // :26
             const V3 sv = (right * tx + up * ty) + N * tz;                       // :27
-            const V3 c = cube_sample(cube, S, sv);                               // :29
+            const V3 c = cube_sample<QUADS>(cube, S, sv);                        // :29
             r0 = r0 + (c.x * ct) * st; r1 = r1 + (c.y * ct) * st; r2 = r2 + (c.z * ct) * st;
         }
         s_row[p][0] = r0; s_row[p][1] = r1; s_row[p][2] = r2;
@@ -266,6 +297,7 @@ VKR_DI V3 ggx_to_world(float4 h, V3 N)                                          
 }
 
 // one wave per output texel: lane l takes samples l, l+64, ... in order; the 64 partials are added in lane order
+template <bool QUADS>
 __global__ __launch_bounds__(256) void k_ibl_prefilter(const float4* cube, int S, const float4* table, uint16_t* out, int Sm)
 {
     __shared__ float4 s_h[IBL_SAMPLES];
@@ -287,7 +319,7 @@ __global__ __launch_bounds__(256) void k_ibl_prefilter(const float4* cube, int S
             const V3 L = normalize3(Hh * (2.0f * dot3(N, Hh)) - N);              // :61 (V = R = N)
             const float NdotL = gmax(dot3(N, L), 0.0f);                          // :63
             if (NdotL > 0.0f) {
-                const V3 c = cube_sample(cube, S, L);
+                const V3 c = cube_sample<QUADS>(cube, S, L);
                 c0 = c0 + c.x * NdotL; c1 = c1 + c.y * NdotL; c2 = c2 + c.z * NdotL;   // :65
                 w = w + NdotL;                                                   // :66
             }
@@ -387,6 +419,23 @@ int ibl_scratch(vkr_ctx* c)
     if (int rc = ibl_hip(c, c->d_ibl_tables.alloc(512 * 2 + IBL_SAMPLES * 4), "hipMalloc(ibl tables)")) return rc;
     return VKR_OK;
 }
+// Footprint table of the environment cube for the convolution kernels (64 B per footprint: 101 MB at 512^2); cubes above
+// 2048^2 (1.6 GB of table) are sampled directly.  Returns the pointer the kernels sample from and whether it is the table.
+constexpr uint32_t IBL_QUADS_MAX = 2048u;
+int ibl_quads(vkr_ctx* c, const float* env_cube, uint32_t S, hipStream_t st, const float4** src, bool* quads)
+{
+    *src = (const float4*)env_cube; *quads = false;
+    if (S > IBL_QUADS_MAX || !c->ibl_quads) return VKR_OK;
+    const size_t n = 6u * (size_t)(S + 1u) * (size_t)(S + 1u);
+    if (c->d_ibl_quads.n < n * 4u) {
+        if (int rc = ibl_hip(c, hipStreamSynchronize(st), "hipStreamSynchronize")) return rc;
+        if (int rc = ibl_hip(c, c->d_ibl_quads.alloc(n * 4u), "hipMalloc(ibl footprint table)")) return rc;
+    }
+    k_ibl_quads<<<(uint32_t)((n + 255u) / 256u), 256, 0, st>>>((const float4*)env_cube, (int)S, c->d_ibl_quads.p);
+    if (int rc = ibl_hip(c, hipGetLastError(), "k_ibl_quads")) return rc;
+    *src = c->d_ibl_quads.p; *quads = true;
+    return VKR_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -433,7 +482,10 @@ int vkr_ibl_irradiance(vkr_ctx* c, const float* env_cube, uint32_t env_size, uin
     hipStream_t st = (hipStream_t)stream;
     float2* tables = (float2*)c->d_ibl_tables.p;
     k_ibl_irr_tables<<<1, 128, 0, st>>>(tables, nphi, ntheta);
-    k_ibl_irradiance<<<6u * size * size, 256, 0, st>>>((const float4*)env_cube, (int)env_size, tables, nphi, ntheta, irradiance, (int)size);
+    const float4* src; bool quads;
+    if (int rc = ibl_quads(c, env_cube, env_size, st, &src, &quads)) return rc;
+    if (quads) k_ibl_irradiance<true><<<6u * size * size, 256, 0, st>>>(src, (int)env_size, tables, nphi, ntheta, irradiance, (int)size);
+    else k_ibl_irradiance<false><<<6u * size * size, 256, 0, st>>>(src, (int)env_size, tables, nphi, ntheta, irradiance, (int)size);
     return ibl_hip(c, hipGetLastError(), "k_ibl_irradiance");
 }
 
@@ -447,13 +499,16 @@ int vkr_ibl_prefilter(vkr_ctx* c, const float* env_cube, uint32_t env_size, uint
     hipStream_t st = (hipStream_t)stream;
     float4* table = (float4*)(c->d_ibl_tables.p + 512 * 2);
     const uint32_t mips = vkr_ibl_prefilter_mip_count(size);
+    const float4* src; bool quads;
+    if (int rc = ibl_quads(c, env_cube, env_size, st, &src, &quads)) return rc;
     size_t base = 0;
     for (uint32_t mip = 0; mip < mips; ++mip) {                    // IblPrecompute.cpp:376-470
         const uint32_t sm = (size >> mip) ? (size >> mip) : 1u;
         const float roughness = (float)mip / (float)(mips - 1 > 1 ? mips - 1 : 1);   // :383
         k_ibl_ggx_table<<<IBL_SAMPLES / 256, 256, 0, st>>>(roughness, table);
         const uint32_t texels = 6u * sm * sm;
-        k_ibl_prefilter<<<(texels + 3u) / 4u, 256, 0, st>>>((const float4*)env_cube, (int)env_size, table, prefilter + base, (int)sm);
+        if (quads) k_ibl_prefilter<true><<<(texels + 3u) / 4u, 256, 0, st>>>(src, (int)env_size, table, prefilter + base, (int)sm);
+        else k_ibl_prefilter<false><<<(texels + 3u) / 4u, 256, 0, st>>>(src, (int)env_size, table, prefilter + base, (int)sm);
         base += (size_t)texels * 4;
     }
     return ibl_hip(c, hipGetLastError(), "k_ibl_prefilter");

@@ -114,6 +114,8 @@ struct vkr_ctx {
 
     // ---- IBL precompute scratch: irradiance sin/cos tables (512 float2) + GGX half-vector table (1024 float4)
     vkr::DevBuf<float> d_ibl_tables;
+    bool ibl_quads = true;             // VKR_IBL_QUADS=0: sample the cube image directly (the path cubes above 2048^2 take)
+    vkr::DevBuf<float4> d_ibl_quads;   // footprint table of the environment cube (4 float4 per bilinear footprint), grow-only
 
     // ---- BVH
     bool has_bvh = false;

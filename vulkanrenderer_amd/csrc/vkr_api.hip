@@ -120,6 +120,7 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     if (const char* e = getenv("VKR_MORTON_EMC")) c->morton_emc = (e[0] == '1');
     if (const char* e = getenv("VKR_TREELETS")) c->treelets = (e[0] != '0');            // "0" = plain Karras tree
     if (const char* e = getenv("VKR_SAH_TOP")) c->sah_top = (e[0] != '0');              // "0" = Morton splits above the treelets
+    if (const char* e = getenv("VKR_IBL_QUADS")) c->ibl_quads = (e[0] != '0');
     if (const char* e = getenv("VKR_VALIDATE_TREE")) c->validate_tree = (e[0] == '1');
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
     if (const char* e = getenv("VKR_SUN_MODE")) c->sun_packets = (e[0] != 'r');         // "ray" = one queue item per ray
@@ -166,7 +167,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
     c->d_ib_infos.release(); c->d_ib_bounds.release(); c->d_ib_flags.release(); c->d_ib_tile.release();
     c->d_ib_counters.release(); c->d_ib_seg_begin.release(); c->d_ib_seg_rank.release(); c->d_ib_spans.release();
-    c->d_ib_order.release(); c->d_ibl_tables.release(); c->d_treelet.release(); c->d_sah.release();
+    c->d_ib_order.release(); c->d_ibl_tables.release(); c->d_ibl_quads.release(); c->d_treelet.release(); c->d_sah.release();
     delete c;
 }
 
