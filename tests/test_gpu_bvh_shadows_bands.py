@@ -121,6 +121,50 @@ def test_bvh_structure_after_build_and_refit(torch_mod):
     ctx.close()
 
 
+@pytest.mark.parametrize("scene_kind", ["street", "tiny", "single"])
+@pytest.mark.parametrize("mode", ["wide", "binary"])
+def test_refit_reproduces_the_build_boxes(torch_mod, scene_kind, mode, monkeypatch):
+    """vkr_bvh_refit works level by level on the wide tree (k_wide_refit_level; VKR_REFIT=binary: binary fit +
+    regather).  min/max are exact, so a refit with the build's own transforms must reproduce the build's nodes bit for
+    bit (the build fitted the binary tree), a refit to moved instances must pass the structure check, and moving back
+    must give the build's nodes again."""
+    from vulkanrenderer_amd import make_street_scene
+    from vulkanrenderer_amd.scenes import Material, Mesh, SceneData, grid_mesh, trs
+    monkeypatch.setenv("VKR_REFIT", mode)
+    if scene_kind == "street":
+        scene = make_street_scene(5, 0.02, "bvh")
+    elif scene_kind == "tiny":
+        scene = SceneData([grid_mesh(1, 2, 0)], [Material()], np.zeros(2, dtype=np.uint32),
+                          np.stack([trs((0, 0, 3), (4, 1, 4)), trs((0.5, 0.7, 3.5), (1, 1, 1))]).astype(np.float32), "tiny")
+    else:
+        g = grid_mesh(1, 1, 0)
+        one = Mesh(g.vertices, g.indices[:3].copy(), 0)
+        scene = SceneData([one], [Material()], np.zeros(1, dtype=np.uint32), np.stack([trs((0, 0, 3), (1, 1, 1))]).astype(np.float32), "single")
+    ctx, rt, gb = _ctx(scene, 32, 32)
+    nodes0, tris0 = rt.download()
+    rt.updateTopLevelAS(scene.instance_mesh, scene.instance_transform)
+    ctx.sync()
+    nodes1, tris1 = rt.download()
+    assert nodes1.tobytes() == nodes0.tobytes() and tris1.tobytes() == tris0.tobytes()
+    rng = np.random.default_rng(11)
+    xf = scene.instance_transform.copy()
+    xf[:, 3] += rng.uniform(-1.0, 1.0, len(xf)).astype(np.float32)
+    xf[:, 7] += rng.uniform(0.0, 0.5, len(xf)).astype(np.float32)
+    rt.updateTopLevelAS(scene.instance_mesh, xf)
+    ctx.sync()
+    nodes2, tris2 = rt.download()
+    assert np.array_equal(nodes0.view(np.uint32)[:, 12:16], nodes2.view(np.uint32)[:, 12:16])
+    if scene_kind != "single":
+        assert nodes2.tobytes() != nodes0.tobytes()
+    moved = type(scene)(scene.meshes, scene.materials, scene.instance_mesh, xf, "moved")
+    _check_bvh_structure(nodes2, tris2, moved, rt.info())
+    rt.updateTopLevelAS(scene.instance_mesh, scene.instance_transform)
+    ctx.sync()
+    nodes3, _ = rt.download()
+    assert nodes3.tobytes() == nodes0.tobytes()
+    ctx.close()
+
+
 @pytest.mark.parametrize("kind", ["tiny", "duplicates", "coplanar_grid", "street", "treelets_off", "many_duplicates", "line",
                                   "sah_off"])
 def test_treelet_rebuild_keeps_the_tree_well_formed(torch_mod, oracle_mod, kind, monkeypatch):

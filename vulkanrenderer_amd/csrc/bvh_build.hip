@@ -960,6 +960,7 @@ struct WideCtl {
     uint32_t level_begin;    // current level = [level_begin, level_end)
     uint32_t level_end;
     uint32_t levels;         // non-empty levels processed
+    uint32_t level_start[72]; // level l = wide nodes [level_start[l], level_start[l + 1]) (the level-by-level refit's work lists)
 };
 
 VKR_DI float half_area(const float4& mn, const float4& mx)
@@ -982,6 +983,8 @@ VKR_DI void cand_box(int c, const float4* node_box, const float4* tris, float pa
 // the frame of their union.  origin = union min; per axis scale = 2^e with 254 * scale >= extent; child plane =
 // fma(q, scale, origin), the SAME expression the traversal evaluates, so the rounding checks below make the
 // decoded box contain the exact one.
+VKR_DI void quantise_wide(float4* node, const float lo[4][3], const float hi[4][3], int ncand, const float ulo[3], const float uhi[3]);
+
 VKR_DI void write_wide_boxes(float4* node, const int cand[4], int ncand, const float4* node_box, const float4* tris,
                              float pad_abs)
 {
@@ -995,6 +998,11 @@ VKR_DI void write_wide_boxes(float4* node, const int cand[4], int ncand, const f
             for (int a = 0; a < 3; ++a) { ulo[a] = __builtin_fminf(ulo[a], lo[k][a]); uhi[a] = __builtin_fmaxf(uhi[a], hi[k][a]); }
         }
     }
+    quantise_wide(node, lo, hi, ncand, ulo, uhi);
+}
+
+VKR_DI void quantise_wide(float4* node, const float lo[4][3], const float hi[4][3], int ncand, const float ulo[3], const float uhi[3])
+{
     float scale[3];
     uint32_t ebits = 0;
 #pragma unroll
@@ -1097,6 +1105,7 @@ __global__ void k_wide_init(WideCtl* ctl, uint32_t* wide_bin)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         ctl->count = 1; ctl->level_begin = 0; ctl->level_end = 1; ctl->levels = 0;
+        ctl->level_start[0] = 0;
         wide_bin[0] = 0;
     }
 }
@@ -1104,7 +1113,10 @@ __global__ void k_wide_init(WideCtl* ctl, uint32_t* wide_bin)
 __global__ void k_wide_next(WideCtl* ctl)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (ctl->level_end > ctl->level_begin) ctl->levels += 1;
+        if (ctl->level_end > ctl->level_begin) {
+            if (ctl->levels < 71u) { ctl->level_start[ctl->levels] = ctl->level_begin; ctl->level_start[ctl->levels + 1u] = ctl->level_end; }
+            ctl->levels += 1;
+        }
         ctl->level_begin = ctl->level_end;
         ctl->level_end = ctl->count;
     }
@@ -1126,6 +1138,48 @@ __global__ __launch_bounds__(256) void k_wide_refit(uint32_t count, const float4
     write_wide_boxes(nodes + (size_t)w * 4, cand, ncand, node_box, tris, pad_abs_of(bnd));
 }
 
+// Refit on the wide tree itself, one launch per level from the deepest up (levels are contiguous index ranges): a leaf
+// child's box is the union of its triangles' padded boxes, an internal child's box is the one its own launch stored.
+// min / max are exact, so these are the boxes the binary fit produces (the same sets of triangles) and the nodes come
+// out bit-identical to k_fit + k_wide_refit -- without the 39-deep chain of atomic hand-offs of the binary fit.
+__global__ __launch_bounds__(256) void k_wide_refit_level(uint32_t begin, uint32_t end, float4* nodes, float4* wide_box,
+                                                          const float4* tris, const BvhBounds* bnd)
+{
+    const uint32_t w = begin + blockIdx.x * 256u + threadIdx.x;
+    if (w >= end) return;
+    float4* node = nodes + (size_t)w * 4;
+    const float4 rf = node[3];
+    const uint32_t ref[4] = {f2u(rf.x), f2u(rf.y), f2u(rf.z), f2u(rf.w)};
+    const float pad_abs = pad_abs_of(bnd);
+    float lo[4][3], hi[4][3];
+    float ulo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, uhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    int ncand = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (ref[k] == VKR_CHILD_NONE) continue;     // used slots are a prefix
+        ncand = k + 1;
+        if ((int)ref[k] < 0) {
+            const uint32_t x = ~ref[k];
+            const uint32_t first = x & 0x0fffffffu, cnt = ((x >> 28) & 7u) + 1u;
+            tri_box(tris, first, pad_abs, lo[k], hi[k]);
+            for (uint32_t j = 1; j < cnt; ++j) {
+                float l2[3], h2[3];
+                tri_box(tris, first + j, pad_abs, l2, h2);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo[k][a] = __builtin_fminf(lo[k][a], l2[a]); hi[k][a] = __builtin_fmaxf(hi[k][a], h2[a]); }
+            }
+        } else {
+            const float4 mn = wide_box[(size_t)ref[k] * 2], mx = wide_box[(size_t)ref[k] * 2 + 1];
+            lo[k][0] = mn.x; lo[k][1] = mn.y; lo[k][2] = mn.z; hi[k][0] = mx.x; hi[k][1] = mx.y; hi[k][2] = mx.z;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ulo[a] = __builtin_fminf(ulo[a], lo[k][a]); uhi[a] = __builtin_fmaxf(uhi[a], hi[k][a]); }
+    }
+    quantise_wide(node, lo, hi, ncand, ulo, uhi);
+    wide_box[(size_t)w * 2] = make_float4(ulo[0], ulo[1], ulo[2], 0.0f);
+    wide_box[(size_t)w * 2 + 1] = make_float4(uhi[0], uhi[1], uhi[2], 0.0f);
+}
+
 // n == 1: a root with one single-triangle leaf
 __global__ void k_single(const float4* tris, float4* nodes, uint4* wide_bref, uint32_t* height_out, WideCtl* ctl,
                          const BvhBounds* bnd)
@@ -1137,6 +1191,7 @@ __global__ void k_single(const float4* tris, float4* nodes, uint4* wide_bref, ui
     wide_bref[0] = make_uint4(~0u, VKR_CHILD_NONE, VKR_CHILD_NONE, VKR_CHILD_NONE);
     *height_out = 1u;
     ctl->count = 1; ctl->levels = 1; ctl->level_begin = 1; ctl->level_end = 1;
+    ctl->level_start[0] = 0; ctl->level_start[1] = 1;
 }
 
 // ---------------------------------------------------------------- scene graph -> instance transforms ----
@@ -1328,6 +1383,15 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     if (n == 1) {
         k_single<<<1, 64, 0, st>>>(c->d_tris.p, c->d_nodes.p, c->d_wide_bref.p, c->d_height.p, (WideCtl*)c->d_wide_ctl.p,
                                    c->d_bounds.p);
+        return hipGetLastError();
+    }
+    if (refit_only && c->refit_wide && c->wide_level_start.size() == (size_t)c->wide_levels + 1u && c->wide_levels > 0u) {
+        // wide boxes live in d_node_box (the binary boxes there are only needed by the collapse of a build)
+        for (uint32_t l = c->wide_levels; l-- > 0u;) {
+            const uint32_t b = c->wide_level_start[l], e = c->wide_level_start[l + 1u];
+            if (e > b)
+                k_wide_refit_level<<<(e - b + 255u) / 256u, 256, 0, st>>>(b, e, c->d_nodes.p, c->d_node_box.p, c->d_tris.p, c->d_bounds.p);
+        }
         return hipGetLastError();
     }
     VKR_TRY(hipMemsetAsync(c->d_flags.p, 0, (size_t)(n - 1) * 4, st));

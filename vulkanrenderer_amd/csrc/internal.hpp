@@ -122,6 +122,8 @@ struct vkr_ctx {
     uint32_t morton_bits = 21;
     uint32_t bvh_height = 0;
     uint32_t wide_count = 0, wide_levels = 0;
+    std::vector<uint32_t> wide_level_start;   // level l = wide nodes [start[l], start[l+1]); filled by vkr_bvh_build
+    bool refit_wide = true;    // refit level by level on the wide tree (VKR_REFIT=binary: binary fit + regather)
     bool bounds_dirty = false;
     bool morton_emc = false;   // extended Morton codes (size component), see k_morton
     bool treelets = true;      // range-local PLOC rebuild of the small subtrees (k_treelet_ploc)

@@ -121,6 +121,7 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     if (const char* e = getenv("VKR_TREELETS")) c->treelets = (e[0] != '0');            // "0" = plain Karras tree
     if (const char* e = getenv("VKR_SAH_TOP")) c->sah_top = (e[0] != '0');              // "0" = Morton splits above the treelets
     if (const char* e = getenv("VKR_IBL_QUADS")) c->ibl_quads = (e[0] != '0');
+    if (const char* e = getenv("VKR_REFIT")) c->refit_wide = (e[0] != 'b');             // "binary" = k_fit + k_wide_refit
     if (const char* e = getenv("VKR_VALIDATE_TREE")) c->validate_tree = (e[0] == '1');
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
     if (const char* e = getenv("VKR_SUN_MODE")) c->sun_packets = (e[0] != 'r');         // "ray" = one queue item per ray
@@ -316,7 +317,7 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     HIP_OR_FAIL(c, c->d_bin_range.alloc(n));
     HIP_OR_FAIL(c, c->d_deposit.alloc(n * 8));
     HIP_OR_FAIL(c, c->d_node_box.alloc(n * 2));
-    HIP_OR_FAIL(c, c->d_wide_ctl.alloc(4));
+    HIP_OR_FAIL(c, c->d_wide_ctl.alloc(4 + 72));
     HIP_OR_FAIL(c, c->d_wide_bin.alloc(n));
     HIP_OR_FAIL(c, c->d_tris.alloc(n * 3));
     HIP_OR_FAIL(c, c->d_perm.alloc(n));
@@ -391,11 +392,13 @@ int vkr_bvh_build(vkr_ctx* c, void* stream)
         c->treelets = want_treelets;
         c->sah_top = want_sah;
         HIP_OR_FAIL(c, we);
-        uint32_t ctl[4] = {0, 0, 0, 0};
-        HIP_OR_FAIL(c, hipMemcpyAsync(ctl, c->d_wide_ctl.p, 16, hipMemcpyDeviceToHost, st));
+        uint32_t ctl[4 + 72] = {0};
+        HIP_OR_FAIL(c, hipMemcpyAsync(ctl, c->d_wide_ctl.p, sizeof(ctl), hipMemcpyDeviceToHost, st));
         HIP_OR_FAIL(c, hipStreamSynchronize(st));
         c->wide_count = ctl[0];
         c->wide_levels = ctl[3];
+        c->wide_level_start.clear();
+        if (c->wide_levels <= 70u) c->wide_level_start.assign(ctl + 4, ctl + 4 + c->wide_levels + 1u);
         // near-first traversal defers at most 3 children per level
         if (3u * c->wide_levels + 1u <= (uint32_t)VKR_MAX_STACK) { c->has_bvh = true; return VKR_OK; }
     }
