@@ -1,4 +1,4 @@
-"""Development aid: build the C3 scene's BVH a few times (for `rocprofv3 --kernel-trace --stats` of the build kernels)."""
+"""Development aid: build (and refit) the C3 scene's BVH a few times (for `rocprofv3 --kernel-trace --stats` of the build kernels)."""
 import os
 import sys
 
@@ -14,6 +14,9 @@ rt.init(scene)
 ctx.sync()
 for _ in range(3):
     rt.rebuild()
+ctx.sync()
+for _ in range(3):
+    rt.updateTopLevelAS(scene.instance_mesh, scene.instance_transform)
 ctx.sync()
 info = rt.info()
 print("wide nodes", info.node_count, "levels", info.height, "binary height", info.binary_height)

@@ -315,18 +315,49 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* keys_
 }
 
 // ---------------------------------------------------------------- triangles in Morton order -------------
-__global__ __launch_bounds__(256) void k_emit_sorted(BuildIn in, const uint32_t* perm, float4* tris)
+// BOUNDS (refit): the scene's triangle bounds are reduced here as well, so the refit does not run a second pass over
+// the instances' triangles just for them (k_bounds; the centroid bounds are only needed by the Morton codes of a build)
+template <bool BOUNDS>
+__global__ __launch_bounds__(256) void k_emit_sorted(BuildIn in, const uint32_t* perm, float4* tris, BvhBounds* out)
 {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= in.tri_count) return;
-    uint32_t flat = perm[i];
-    TriW t = emit_tri(in, flat);
-    V3 e1 = t.v1 - t.v0, e2 = t.v2 - t.v0;
-    uint32_t cls = in.mesh_class[t.mesh];
-    float4* o = tris + (size_t)i * 3;
-    o[0] = make_float4(t.v0.x, t.v0.y, t.v0.z, u2f((t.mesh & 0x0fffffffu) | (cls << 28)));
-    o[1] = make_float4(e1.x, e1.y, e1.z, u2f(t.prim));
-    o[2] = make_float4(e2.x, e2.y, e2.z, u2f(flat));
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (i < in.tri_count) {
+        uint32_t flat = perm[i];
+        TriW t = emit_tri(in, flat);
+        V3 e1 = t.v1 - t.v0, e2 = t.v2 - t.v0;
+        uint32_t cls = in.mesh_class[t.mesh];
+        float4* o = tris + (size_t)i * 3;
+        o[0] = make_float4(t.v0.x, t.v0.y, t.v0.z, u2f((t.mesh & 0x0fffffffu) | (cls << 28)));
+        o[1] = make_float4(e1.x, e1.y, e1.z, u2f(t.prim));
+        o[2] = make_float4(e2.x, e2.y, e2.z, u2f(flat));
+        if (BOUNDS) {
+            lo[0] = __builtin_fminf(t.v0.x, __builtin_fminf(t.v1.x, t.v2.x)); hi[0] = __builtin_fmaxf(t.v0.x, __builtin_fmaxf(t.v1.x, t.v2.x));
+            lo[1] = __builtin_fminf(t.v0.y, __builtin_fminf(t.v1.y, t.v2.y)); hi[1] = __builtin_fmaxf(t.v0.y, __builtin_fmaxf(t.v1.y, t.v2.y));
+            lo[2] = __builtin_fminf(t.v0.z, __builtin_fminf(t.v1.z, t.v2.z)); hi[2] = __builtin_fmaxf(t.v0.z, __builtin_fmaxf(t.v1.z, t.v2.z));
+        }
+    }
+    if (BOUNDS) {
+        __shared__ float red[4][6];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = wave_min(lo[k]), b = wave_max(hi[k]);
+            if (lane == 0) { red[wave][k] = a; red[wave][3 + k] = b; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const int k = threadIdx.x;
+            float v = red[0][k];
+            for (int w = 1; w < 4; ++w) v = k < 3 ? __builtin_fminf(v, red[w][k]) : __builtin_fmaxf(v, red[w][k]);
+            if (v > -3.0e38f && v < 3.0e38f) {
+                // 10 k blocks: only the few that improve a bound issue the atomic (a stale read only costs a redundant one)
+                const uint32_t e = enc_f(v);
+                if (k < 3) { if (e < __hip_atomic_load(&out->tri_min[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&out->tri_min[k], e); }
+                else { if (e > __hip_atomic_load(&out->tri_max[k - 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out->tri_max[k - 3], e); }
+            }
+        }
+    }
 }
 
 #ifndef VKR_TL_MAX
@@ -1142,11 +1173,8 @@ __global__ __launch_bounds__(256) void k_wide_refit(uint32_t count, const float4
 // child's box is the union of its triangles' padded boxes, an internal child's box is the one its own launch stored.
 // min / max are exact, so these are the boxes the binary fit produces (the same sets of triangles) and the nodes come
 // out bit-identical to k_fit + k_wide_refit -- without the 39-deep chain of atomic hand-offs of the binary fit.
-__global__ __launch_bounds__(256) void k_wide_refit_level(uint32_t begin, uint32_t end, float4* nodes, float4* wide_box,
-                                                          const float4* tris, const BvhBounds* bnd)
+VKR_DI void wide_refit_node(uint32_t w, float4* nodes, float4* wide_box, const float4* tris, const BvhBounds* bnd)
 {
-    const uint32_t w = begin + blockIdx.x * 256u + threadIdx.x;
-    if (w >= end) return;
     float4* node = nodes + (size_t)w * 4;
     const float4 rf = node[3];
     const uint32_t ref[4] = {f2u(rf.x), f2u(rf.y), f2u(rf.z), f2u(rf.w)};
@@ -1178,6 +1206,13 @@ __global__ __launch_bounds__(256) void k_wide_refit_level(uint32_t begin, uint32
     quantise_wide(node, lo, hi, ncand, ulo, uhi);
     wide_box[(size_t)w * 2] = make_float4(ulo[0], ulo[1], ulo[2], 0.0f);
     wide_box[(size_t)w * 2 + 1] = make_float4(uhi[0], uhi[1], uhi[2], 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_wide_refit_level(uint32_t begin, uint32_t end, float4* nodes, float4* wide_box,
+                                                          const float4* tris, const BvhBounds* bnd)
+{
+    const uint32_t w = begin + blockIdx.x * 256u + threadIdx.x;
+    if (w < end) wide_refit_node(w, nodes, wide_box, tris, bnd);
 }
 
 // n == 1: a root with one single-triangle leaf
@@ -1318,8 +1353,9 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     in.inst_xf = c->d_inst_xf.p; in.instance_count = c->instance_count; in.tri_count = n;
     const uint32_t nb = (n + 255u) / 256u;
 
-    k_bounds_init<<<1, 64, 0, st>>>(c->d_bounds.p);   // also on refit: transforms move the scene, and the
-    k_bounds<<<nb < 1024u ? nb : 1024u, 256, 0, st>>>(in, c->d_bounds.p);   // conservative padding scales with its extent
+    k_bounds_init<<<1, 64, 0, st>>>(c->d_bounds.p);   // also on refit: transforms move the scene, and the conservative
+    if (!refit_only)                                  // padding scales with its extent (refit: reduced in k_emit_sorted)
+        k_bounds<<<nb < 1024u ? nb : 1024u, 256, 0, st>>>(in, c->d_bounds.p);
     if (!refit_only) {
         const int emc = c->morton_emc ? 1 : 0;
         const uint32_t mbits = emc ? (c->morton_bits > 15u ? 15u : c->morton_bits) : c->morton_bits;
@@ -1370,7 +1406,8 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
             k_hierarchy<<<(n - 1 + 255u) / 256u, 256, 0, st>>>(c->d_keys[cur].p, (int)n, c->d_bin_child.p,
                                                              c->d_bin_range.p, c->d_leaf_parent.p, c->d_node_parent.p);
     }
-    k_emit_sorted<<<nb, 256, 0, st>>>(in, c->d_perm.p, c->d_tris.p);
+    if (refit_only) k_emit_sorted<true><<<nb, 256, 0, st>>>(in, c->d_perm.p, c->d_tris.p, c->d_bounds.p);
+    else k_emit_sorted<false><<<nb, 256, 0, st>>>(in, c->d_perm.p, c->d_tris.p, c->d_bounds.p);
     if (!refit_only && n >= (uint32_t)TL_MIN && c->treelets) {
         if (c->d_treelet.n < (size_t)n + 2) VKR_TRY(c->d_treelet.alloc((size_t)n + 2));
         VKR_TRY(hipMemsetAsync(c->d_treelet.p, 0, 8, st));
@@ -1387,6 +1424,7 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     }
     if (refit_only && c->refit_wide && c->wide_level_start.size() == (size_t)c->wide_levels + 1u && c->wide_levels > 0u) {
         // wide boxes live in d_node_box (the binary boxes there are only needed by the collapse of a build)
+        // one launch per level (batching the small levels into single-block launches with barriers was slower: 0.68 ms)
         for (uint32_t l = c->wide_levels; l-- > 0u;) {
             const uint32_t b = c->wide_level_start[l], e = c->wide_level_start[l + 1u];
             if (e > b)
