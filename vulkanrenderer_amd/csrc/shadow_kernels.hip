@@ -631,11 +631,13 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
     // the persistent waves still get several chunks each; per-pixel results do not depend on it.
     __shared__ uint32_t s_nq[SP_NQ];       // node items: pixel << 22 | node
     __shared__ uint32_t s_lq[KQ_LQ];       // leaf items: leaf reference ...
-    __shared__ uint16_t s_lqp[KQ_LQ];      // ... and its pixel
+    __shared__ uint8_t s_lqp[KQ_LQ];       // ... and its pixel (index in the chunk: a byte; the LDS footprint decides how
+                                           // many waves a CU holds: 6 656 B = 24 of them, 7 424 B were 22)
+    static_assert(SP_PIX <= 256, "pixel indices are stored in bytes");
     __shared__ uint32_t s_mask[SP_PIX];    // per pixel: bit k = sample k is occluded
-    __shared__ float4 s_org[SP_PIX];       // per pixel: ray origin
+    __shared__ float s_ox[SP_PIX], s_oy[SP_PIX], s_oz[SP_PIX];   // per pixel: ray origin
     __shared__ uint32_t s_tq[SP_TQ];       // triangle items (leaf triangles that passed the cone pre-filter): triangle ...
-    __shared__ uint16_t s_tqp[SP_TQ];      // ... and its pixel
+    __shared__ uint8_t s_tqp[SP_TQ];       // ... and its pixel
 
     const int lane = threadIdx.x;
     const char* node_base = (const char*)sc.nodes;
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                     V3 worldPos = V3{sa.wp[3 * (size_t)i], sa.wp[3 * (size_t)i + 1], sa.wp[3 * (size_t)i + 2]};
                     V3 geomNormal = V3{sa.ng[3 * (size_t)i], sa.ng[3 * (size_t)i + 1], sa.ng[3 * (size_t)i + 2]};
                     V3 rayOrigin = worldPos + geomNormal * 0.002f;                // :224-225
-                    s_org[p] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
+                    s_ox[p] = rayOrigin.x; s_oy[p] = rayOrigin.y; s_oz[p] = rayOrigin.z;
                     live = true;
 #ifdef VKR_SUN_STATS
                     st_pix++;
@@ -704,8 +706,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
 #ifdef VKR_SUN_STATS
                         st_tri++;
 #endif
-                        const float4 o = s_org[pix];
-                        const V3 ro = V3{o.x, o.y, o.z};
+                        const V3 ro = V3{s_ox[pix], s_oy[pix], s_oz[pix]};
                         const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
                         const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
                         const V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
@@ -746,8 +747,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                     if ((s_mask[pix] & full) != full) {
                         const uint32_t x = ~ref;
                         first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
-                        const float4 o = s_org[pix];
-                        ro = V3{o.x, o.y, o.z};
+                        ro = V3{s_ox[pix], s_oy[pix], s_oz[pix]};
                     }
                 }
                 for (uint32_t j = 0; j < (uint32_t)VKR_LEAF_MAX; ++j) {
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                         keep = !(perp2 > lim * lim);                                 // NaN keeps
                     }
                     const unsigned long long km = __ballot(keep);
-                    if (keep) { const uint32_t ix = tq + mbcnt64(km); s_tq[ix] = first + j; s_tqp[ix] = (uint16_t)pix; }
+                    if (keep) { const uint32_t ix = tq + mbcnt64(km); s_tq[ix] = first + j; s_tqp[ix] = (uint8_t)pix; }
                     tq += (uint32_t)__popcll(km);
                 }
                 continue;
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
             const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
             const float4* np = (const float4*)(node_base + ((size_t)node << 6));
             const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            const float4 o = s_org[pix];
+            const V3 o = V3{s_ox[pix], s_oy[pix], s_oz[pix]};
             const uint32_t eb = f2u(q0.w);
             const float sx = u2f((eb & 0xffu) << 23), sy = u2f(((eb >> 8) & 0xffu) << 23), sz = u2f(((eb >> 16) & 0xffu) << 23);
             // plane - origin per axis: fma(q, s, node origin - ray origin)
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
         const unsigned long long hm = __ballot(HC), lm = __ballot((int)RC < 0);                                     \
         const unsigned long long mn = hm & ~lm, ml = hm & lm;                                                       \
         if (HC) {                                                                                                   \
-            if ((int)RC < 0) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqp[ix] = (uint16_t)pix; }    \
+            if ((int)RC < 0) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqp[ix] = (uint8_t)pix; }     \
             else s_nq[nq + mbcnt64(mn)] = (pix << KQ_NODE_BITS) | RC;                                               \
         }                                                                                                           \
         nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
