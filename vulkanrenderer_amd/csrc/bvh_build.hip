@@ -1,12 +1,14 @@
-// bvh_build.hip -- GPU LBVH build / refit.  Replaces the driver's acceleration-structure builder behind
+// bvh_build.hip -- GPU acceleration-structure build / refit.  Replaces the driver's acceleration-structure builder behind
 // RayTracingContext::buildBottomLevelASes / buildTopLevelAS / updateTopLevelAS
 // (RayTracingContext.cpp:199-345, 165-197).
 //
 // The reference is two-level (one BLAS per mesh + a TLAS of instances).  Here instances are flattened to
-// world-space triangles (instanced meshes are duplicated) and ONE binary LBVH is built over them:
+// world-space triangles (instanced meshes are duplicated) and ONE tree is built over them:
 //   bounds -> Morton codes (21 or 10 bits/axis) -> LSD radix sort (8-bit digits, LDS ranking)
-//   -> Karras 2012 hierarchy -> bottom-up AABB fit (atomic arrival flags).
-// Refit = re-transform the triangles in the stored Morton order + the same bottom-up fit.
+//   -> binned-SAH splits of every range above 1024 triangles (path bits go in front of the Morton bits, 4 more sort passes)
+//   -> Karras 2012 hierarchy -> PLOC rebuild of the subtrees of <= 1024 triangles (LDS) -> bottom-up AABB fit (atomic
+//   arrival flags) -> breadth-first collapse into 4-ary nodes with 8-bit quantised child boxes (traverse.hpp layout).
+// Refit = re-transform the triangles in the stored order + a level-by-level refit of the 4-ary tree (topology kept).
 #include <stdio.h>
 
 #include "internal.hpp"
