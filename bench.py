@@ -501,6 +501,10 @@ def main():
         if shadows is not None:
             ts = [event_time_ms(lambda: (setattr(shadows, "gb", gbs[i]), shadows.sun(ubos[i])), None) for i in range(Wu, Wu + min(K, 5))]
             out["kernels"]["sun_shadow_ms_full_frame"] = float(np.mean(ts))
+            # K5, not part of the timed workload (the reference's default point-light count is 0, AppConfig.h:99): one
+            # point light's shadow rays over the whole frame (pbr.frag:169-196, light 0 of FrameManager.cpp:477-483)
+            tp = [event_time_ms(lambda: (setattr(shadows, "gb", gbs[i]), shadows.point(ubos[i], 0)), None) for i in range(Wu, Wu + min(K, 5))]
+            out["kernels"]["point_shadow_ms_full_frame_per_light"] = float(np.mean(tp))
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
