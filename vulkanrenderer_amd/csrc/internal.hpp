@@ -154,6 +154,7 @@ struct vkr_ctx {
     vkr::DevBuf<float4> d_raybuf;            // K1 ray slices: per wave (2 float4/ray + retry list), grow-only
     vkr::DevBuf<uint32_t> d_tile_counter;    // K1 persistent waves pull tiles from it
     vkr::DevBuf<uint8_t> d_sun_frame;        // K4 packet form: the frame's sample directions (SunFrame)
+    int sun_reserve_waves = 4;               // K4 packet form: wave slots per CU left free (VKR_SUN_RESERVE_WAVES)
     vkr::DevBuf<uint32_t> d_sun_counter;     // K4 packet form: chunk counter of its persistent waves (separate from K1's)
     bool sun_packets = true;                 // K4 form: one packet per pixel (k_shadow_sun_pkt) or one item per ray (k_shadow_q)
     bool trace_streaming = true;             // K1 form: wave-wide queues (k_trace_q) or one ray per lane (k_trace)
