@@ -384,7 +384,7 @@ typedef struct vkr_trace_stats {
     uint64_t tris_tested;   /* ray/triangle tests                           */
     uint64_t wave_node_iters; /* node-loop iterations counted once per wave (lane utilisation = nodes_visited / (64*this)) */
     uint64_t wave_tri_iters;  /* triangle-loop iterations counted once per wave */
-    uint64_t overflow_tiles;  /* reserved (always 0): deep rays spill to per-lane scratch inside the same kernel */
+    uint64_t overflow_tiles;  /* K1 queue items that took the wave's global overflow stack instead of LDS (a performance counter, not an error) */
 } vkr_trace_stats;
 /* Enable (1) / disable (0) traversal counters for subsequent AO traces (slower kernel variant), and read
  * them back (synchronises).  Feeds bench.py's algorithmic-bytes figure. */

@@ -61,17 +61,16 @@ def _check_bvh_structure(nodes_f, tris_f, scene, info):
         """-> (min, max) true bounds of the triangles under ref"""
         nonlocal depth_max
         if ref < 0:
-            x = (~ref) & 0xffffffff
-            first, cnt = x & 0x0fffffff, ((x >> 28) & 7) + 1
-            assert cnt <= 4 and first + cnt <= T
+            x = ref & 0x7fffffff                      # leaf: bit 31 set, bits 30..1 first triangle, bit 0 count - 1
+            first, cnt = x >> 1, (x & 1) + 1
+            assert first + cnt <= T
             seen_tri[first:first + cnt] += 1
             return tmin[first:first + cnt].min(axis=0), tmax[first:first + cnt].max(axis=0)
         seen_node[ref] += 1
         n = nodes_u[ref]
         org = nodes_f[ref, 0:3].astype(np.float64)
-        eb = int(n[3])
-        sc = np.array([2.0 ** ((eb >> (8 * k) & 0xff) - 127) for k in range(3)])
-        nchild = eb >> 24
+        sc = np.array([nodes_f[ref, 10], nodes_f[ref, 11], nodes_f[ref, 3]], dtype=np.float64)   # scale x, y | z: powers of two
+        assert np.all(sc > 0) and np.all(np.log2(sc) == np.round(np.log2(sc)))
         qmin = np.array([[(int(n[4 + a]) >> (8 * c)) & 0xff for a in range(3)] for c in range(4)], dtype=np.float64)
         qmax = np.array([[(int(n[(7, 8, 9)[a]]) >> (8 * c)) & 0xff for a in range(3)] for c in range(4)], dtype=np.float64)
         lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
@@ -86,7 +85,7 @@ def _check_bvh_structure(nodes_f, tris_f, scene, info):
             bmin, bmax = org + qmin[c] * sc, org + qmax[c] * sc
             assert np.all(bmin <= lo) and np.all(bmax >= hi), f"node {ref} slot {c} does not enclose its subtree"
             lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
-        assert used == nchild and used >= 1
+        assert used >= 1
         return lo_all, hi_all
 
     import sys
@@ -561,7 +560,7 @@ def test_full_size_properties_1080p(torch_mod):
             st = trace_stats(ctx, reset=True)
             nvalid = int(valid.sum())
             assert 8 * nvalid <= st.rays <= 16 * nvalid            # one ray per sample + at most one retry each
-            assert st.nodes_visited >= st.rays and st.overflow_tiles == 0
+            assert st.nodes_visited >= st.rays and st.overflow_tiles <= st.nodes_visited // 100   # queue spills to the global stack stay rare
             trace_stats_enable(ctx, False)
         if prev is not None:
             deltas.append(float(np.abs(ao - prev).mean()))

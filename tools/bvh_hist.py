@@ -14,8 +14,8 @@ used = refs != 0x7fffffff
 nch = used.sum(axis=1)
 print("nodes", len(nodes), "children/node hist", np.bincount(nch, minlength=5), "mean", nch.mean())
 leaf = used & (refs < 0)
-x = (~refs[leaf]).astype(np.uint32)
-cnt = ((x >> 28) & 7) + 1
+x = refs[leaf].astype(np.uint32)          # leaf: bit 31 set, bits 30..1 first triangle, bit 0 count - 1
+cnt = (x & 1) + 1
 print("leaves", leaf.sum(), "tris/leaf hist", np.bincount(cnt, minlength=5), "mean", cnt.mean())
 nl = leaf.sum(axis=1); ni = (used & (refs >= 0)).sum(axis=1)
 print("nodes with only leaf children", (ni == 0).sum(), "their child hist", np.bincount(nch[ni == 0], minlength=5))

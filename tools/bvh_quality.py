@@ -25,8 +25,7 @@ nodes, tris = rt.download()
 nu = nodes.view(np.uint32)
 N = len(nodes)
 org = nodes[:, 0:3].astype(np.float64)
-eb = nu[:, 3]
-sc = np.stack([2.0 ** (((eb >> (8 * k)) & 0xff).astype(np.float64) - 127) for k in range(3)], axis=1)
+sc = np.stack([nodes[:, 10], nodes[:, 11], nodes[:, 3]], axis=1).astype(np.float64)   # scale x, y | z stored as floats
 def planes(wordcols):
     out = np.zeros((N, 4, 3))
     for a, col in enumerate(wordcols):

@@ -1037,7 +1037,6 @@ VKR_DI void write_wide_boxes(float4* node, const int cand[4], int ncand, const f
 VKR_DI void quantise_wide(float4* node, const float lo[4][3], const float hi[4][3], int ncand, const float ulo[3], const float uhi[3])
 {
     float scale[3];
-    uint32_t ebits = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float ext = (uhi[a] - ulo[a]) * (1.0f / 254.0f);
@@ -1047,7 +1046,6 @@ VKR_DI void quantise_wide(float4* node, const float lo[4][3], const float hi[4][
         if (e < 27u) e = 27u;
         if (e > 254u) e = 254u;
         scale[a] = u2f(e << 23);
-        ebits |= e << (8 * a);
     }
     uint32_t q[6] = {0, 0, 0, 0, 0, 0};   // qminx, qminy, qminz, qmaxx, qmaxy, qmaxz : one byte per child
 #pragma unroll
@@ -1070,9 +1068,9 @@ VKR_DI void quantise_wide(float4* node, const float lo[4][3], const float hi[4][
             q[3 + a] |= qh << (8 * k);
         }
     }
-    node[0] = make_float4(ulo[0], ulo[1], ulo[2], u2f(ebits | ((uint32_t)ncand << 24)));
+    node[0] = make_float4(ulo[0], ulo[1], ulo[2], scale[2]);
     node[1] = make_float4(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3]));
-    node[2] = make_float4(u2f(q[4]), u2f(q[5]), 0.0f, 0.0f);
+    node[2] = make_float4(u2f(q[4]), u2f(q[5]), scale[0], scale[1]);
 }
 
 __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bin_child, const uint2* bin_range,
@@ -1126,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bi
                 ref[k] = idx;
             } else {
                 uint32_t first = (c >= 0) ? bin_range[c].x : (uint32_t)(~c);
-                ref[k] = ~(first | ((cnt - 1u) << 28));
+                ref[k] = leaf_ref_make(first, cnt);
             }
         }
     }
@@ -1189,8 +1187,7 @@ VKR_DI void wide_refit_node(uint32_t w, float4* nodes, float4* wide_box, const f
         if (ref[k] == VKR_CHILD_NONE) continue;     // used slots are a prefix
         ncand = k + 1;
         if ((int)ref[k] < 0) {
-            const uint32_t x = ~ref[k];
-            const uint32_t first = x & 0x0fffffffu, cnt = ((x >> 28) & 7u) + 1u;
+            const uint32_t first = leaf_ref_first(ref[k]), cnt = leaf_ref_count(ref[k]);
             tri_box(tris, first, pad_abs, lo[k], hi[k]);
             for (uint32_t j = 1; j < cnt; ++j) {
                 float l2[3], h2[3];
@@ -1224,7 +1221,7 @@ __global__ void k_single(const float4* tris, float4* nodes, uint4* wide_bref, ui
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int cand[4] = {~0, 0, 0, 0};
     write_wide_boxes(nodes, cand, 1, nullptr, tris, pad_abs_of(bnd));
-    nodes[3] = make_float4(u2f(~0u), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE));
+    nodes[3] = make_float4(u2f(leaf_ref_make(0u, 1u)), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE), u2f(VKR_CHILD_NONE));
     wide_bref[0] = make_uint4(~0u, VKR_CHILD_NONE, VKR_CHILD_NONE, VKR_CHILD_NONE);
     *height_out = 1u;
     ctl->count = 1; ctl->levels = 1; ctl->level_begin = 1; ctl->level_end = 1;

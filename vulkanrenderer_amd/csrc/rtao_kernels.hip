@@ -100,7 +100,7 @@ VKR_DI bool computePrevUv(const float* prevViewProj, V3 worldPos, V2* prevUv)  /
 // The short stack spills to per-lane scratch beyond VKR_LDS_STACK entries; the spill path is entered only by a
 // lane about to run past the LDS part, so it stays out of the common instruction stream.
 // ---------------------------------------------------------------------------------------------
-constexpr int CUR_DONE = (int)0x80000000;
+constexpr int CUR_DONE = -1;   // not a leaf reference: it would name triangle 2^30 - 1 (the scene limit is 2^28)
 
 constexpr int K1_BLOCK = 64;
 
@@ -415,9 +415,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
                     // near/far byte-quads once per axis, so no per-plane min/max; unused slots are stored inverted
                     // (qmin = 255, qmax = 0) and miss by themselves.  Rounding of this form is covered by the leaf
                     // padding (bvh_build.hip tri_box) and by the outward quantisation.
-                    const uint32_t eb = f2u(q0.w);
-                    const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
-                                az = u2f(((eb >> 16) & 0xffu) << 23) * id.z;
+                    const float ax = q2.z * id.x, ay = q2.w * id.y, az = q0.w * id.z;   // scales are stored as floats
                     const float bx = (q0.x - ro.x) * id.x, by = (q0.y - ro.y) * id.y, bz = (q0.z - ro.z) * id.z;
                     const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
                     const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
@@ -463,8 +461,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
                 }
             } else if (pend0 != CUR_DONE) {
                 // ---- leaf: ONE triangle per step (queryAoClosestHit :125-182, closest committed hit)
-                uint32_t x = (uint32_t)(~pend0);
-                uint32_t first = x & 0x0fffffffu, rest = (x >> 28) & 7u;     // rest = triangles after this one
+                uint32_t first = leaf_ref_first((uint32_t)pend0), rest = leaf_ref_count((uint32_t)pend0) - 1u;   // rest = triangles after this one
                 {
                     const float4* tp = (const float4*)(tri_base + (size_t)first * 48u);
                     float4 a = tp[0], b = tp[1], c = tp[2];
@@ -485,7 +482,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
                     if (hit && cls == 2u) hit = alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), u, v);
                     if (hit) { tbest = t; found = true; }
                 }
-                if (rest != 0u) pend0 = (int)(~((first + 1u) | ((rest - 1u) << 28)));
+                if (rest != 0u) pend0 = (int)leaf_ref_make(first + 1u, rest);
                 else { pend0 = pend1; pend1 = CUR_DONE; }
             }
             // ---- a leaf in hand moves to a free parking slot; the lane then continues with the next stack entry
@@ -531,108 +528,168 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 
 
 // ---------------------------------------------------------------------------------------------
-// K1, streaming form (the default).  Persistent waves pull 8x8 tiles from a counter; inside a tile the rays do not
-// own lanes: work lives in two wave-wide LIFO queues in LDS,
-//     node items (wide node, ray)   and   leaf items (leaf, ray),
-// and every step pops up to 64 items of ONE kind, so node steps and leaf steps both run with (nearly) all lanes
-// busy -- the per-lane state machine above keeps 50-60 % of the lanes busy because a lane holds either node work
-// or triangle work, rarely both.  A node step tests the four child boxes against [tmin, closest hit so far] and
-// appends the hit children to the two queues (ballot + mbcnt compaction); a leaf step tests the leaf's triangles
-// and lowers the ray's closest hit with an LDS atomic min on the float bits.  No ordering, no per-lane stack:
-// the closest committed hit does not depend on the order triangles are met in, and AO rays mostly miss, so
-// near-first ordering would buy little.  The self-hit retry (:193-200) is a second round over the rays that
-// need it.  The node queue cannot overflow: a step pops n items and pushes at most 4n, so n shrinks as the queue
-// fills, down to one item per step = strict depth-first, whose growth is bounded by 3 x tree depth (KQ_GUARD).
+// K1, streaming form (the default).  Persistent single-wave workgroups pull work items -- a block of P pixels with
+// all their rays, at most 2^RB rays -- from a counter; inside an item the rays do not own lanes: work lives in wave-wide
+// LIFO queues in LDS,
+//     node items  ray << (32-RB) | wide node          leaf items  ray << (32-RB) | first triangle << 1 | count-1
+// and every step pops items of ONE kind, so node steps and leaf steps both run with (nearly) all lanes busy.  A node
+// step tests the four child boxes against [tmin, closest hit so far] and appends the hit children to the two queues
+// (ballot + mbcnt compaction; a leaf reference becomes a leaf item with one add); a leaf step tests the leaf's
+// triangles and lowers the ray's closest hit with an LDS atomic min on the float bits; MASK candidates queue up
+// once more and are alpha-tested a wave at a time.  No ordering, no per-lane stack: the closest committed hit does
+// not depend on the order triangles are met in.  The self-hit retry (:193-200) is a second round over the rays that
+// need it.
+//
+// Round-2 shape ("fat waves"): 3 waves per SIMD instead of 6, each with twice the work in flight --
+//   * a node step pops up to 128 items, two per lane, and issues both node fetches before the first slab test;
+//   * the ray records the node step needs ({origin | tMin}, {1/direction | closest hit}) live in LDS (8 KB per wave)
+//     instead of a 24 KB global slice per wave that the 6144 resident waves kept evicting from L2 (0.9 GB written and
+//     2.5 GB fetched per frame in round 1); only the direction (leaf steps) stays in global memory;
+//   * <= 168 VGPRs: nothing spills (round 1: 80 VGPRs, 26 spilled, 116 SGPRs spilled into VGPR lanes);
+//   * queue overflow goes to a small global stack per wave instead of sizing the LDS queues for the worst case, and
+//     the step width is throttled only when LDS + global capacity could run out (strict depth-first bound).
 // ---------------------------------------------------------------------------------------------
-struct QSliceLayout { uint32_t rays_f4, retry_f4, total_f4; };   // per-wave global scratch, in float4 units
-__host__ __device__ inline QSliceLayout q_slice_layout(int rayCount)
-{
-    QSliceLayout l;
-    l.rays_f4 = (uint32_t)rayCount * 64u * 3u;    // {origin | tMin}, {direction | -}, {1/direction | -} per ray
-    l.retry_f4 = (uint32_t)rayCount * 16u;        // one u32 per ray
-    l.total_f4 = l.rays_f4 + l.retry_f4;
-    return l;
-}
-
-// Occupancy of k_trace_q is set by LDS and VGPRs together; measured best on MI355X at 8 rays/px: 640 node items
-// (7.3 KB of LDS per wave -> 22 waves per CU) and a VGPR budget for 6 waves per SIMD.
-#ifndef VKR_Q_WAVES
-#define VKR_Q_WAVES 6
+#ifndef K1_WAVES
+#define K1_WAVES 5         // resident waves per SIMD the kernel is compiled for (VGPR budget 512 / K1_WAVES)
+#endif
+#ifndef K1_RB
+#define K1_RB 7            // ray bits of an item at most: 2^K1_RB rays (32 B of LDS each)
+#endif
+#ifndef K1_STEP
+#define K1_STEP 64u        // node items per step: 64 (one per lane) or 128 (two per lane)
 #endif
 #ifndef K1_NQ
-#define K1_NQ 640
+#define K1_NQ 512          // node queue entries in LDS
 #endif
-// Pixels per work item of k_trace_q: 64 (8x8) or 32 (8x4; lanes 32..63 mirror the pixels of lanes 0..31 and generate
-// the odd rays, lanes 0..31 resolve).  Smaller items shorten the drain of the persistent launch.
-#ifndef K1_TILE_PX
-#define K1_TILE_PX 32
+#ifndef K1_CHUNK
+#define K1_CHUNK 1         // work items a wave pulls from the counter at a time
 #endif
-template <bool STATS>
-__global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_WAVES, VKR_Q_WAVES))) void k_trace_q(SceneDev sc, FrameParams fp, const uint16_t* depthP,
-                                                      const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
-                                                      int y0, int y1, uint32_t tiles_x, uint32_t n_tiles, float4* rayBuf,
-                                                      uint32_t* tile_counter, unsigned long long* stats)
-{
-    extern __shared__ uint32_t smem[];
-    const int rayCount = fp.rayCount;                                           // :252
-    uint32_t* s_tbest = smem;                                                   // [rayCount * K1_TILE_PX] closest hit, float bits
-    uint32_t* s_nq = smem + (uint32_t)rayCount * (uint32_t)K1_TILE_PX;                           // node items: ray << 22 | node
-    uint32_t* s_lq = s_nq + K1_NQ;                                              // leaf items: leaf reference ...
-    uint16_t* s_lqr = (uint16_t*)(s_lq + KQ_LQ);                                // ... and its ray
-    uint32_t* s_aq = (uint32_t*)(s_lqr + KQ_LQ);                                // MASK candidates: triangle index ...
-    uint16_t* s_aqr = (uint16_t*)(s_aq + KQ_AQ);                                // ... and its ray
+#ifndef K1_LQ
+#define K1_LQ 256          // leaf queue entries in LDS (>= 64; a node step's leaf pushes beyond it go to the global stack)
+#endif
+constexpr uint32_t K1_GNQ = 4096;      // node-item overflow stack per wave (global)
+constexpr uint32_t K1_GLQ = 512;       // leaf-item overflow per wave (global): one node step pushes <= 4 * 128
+constexpr uint32_t K1_AQ = 128;        // alpha-test queue (LDS): drained whenever it holds a full wave of candidates
 
+struct QSliceLayout { uint32_t dir_f4, retry_f4, gnq_f4, glq_f4, total_f4; };   // per-wave global scratch, in float4 units
+__host__ __device__ inline QSliceLayout q_slice_layout(int rb)
+{
+    QSliceLayout l;
+    const uint32_t rays = 1u << rb;
+    l.dir_f4 = rays;                  // {direction | tMin as generated} per ray
+    l.retry_f4 = rays / 4u;           // one u32 per ray
+    l.gnq_f4 = K1_GNQ / 4u;
+    l.glq_f4 = K1_GLQ / 4u;
+    l.total_f4 = l.dir_f4 + l.retry_f4 + l.gnq_f4 + l.glq_f4;
+    return l;
+}
+__host__ __device__ inline size_t q_lds_bytes(int rb)
+{
+    return (size_t)(1u << rb) * 32u + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u;
+}
+// pixels per work item: the largest power of two <= 64 with P * rayCount <= 2^RB
+__host__ __device__ inline int q_item_pixels(int rb, int rayCount)
+{
+    int p = 64;
+    while (p > 1 && p * rayCount > (1 << rb)) p >>= 1;
+    return p;
+}
+
+// v_max3 / v_min3 / v_max / v_min as they are: __builtin_fmaxf makes hipcc quiet its operands first (v_max x, x), eight
+// extra instructions per node step.  The slab values are never signalling NaNs.
+VKR_DI float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+VKR_DI float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+VKR_DI float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+VKR_DI float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+struct NodeIn { float4 a, b, q0, q1, q2, q3; uint32_t rayhi; };   // one popped node item with its operands in flight
+
+template <bool STATS, int RB>
+__global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k_trace_q(
+    SceneDev sc, FrameParams fp, const uint16_t* depthP, const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
+    int y0, int y1, uint32_t tiles_x, uint32_t n_items, float4* rayBuf, uint32_t* tile_counter, unsigned long long* stats)
+{
+    constexpr uint32_t RAYS = 1u << RB;
+    constexpr uint32_t SH = 32u - (uint32_t)RB;              // item = ray << SH | payload
+    constexpr uint32_t PMASK = (1u << SH) - 1u;
+    extern __shared__ float4 smem4[];
+    float4* s_ra = smem4;                                     // [RAYS] origin.xyz | tMin        (round 1: advanced origin | tMin')
+    float4* s_rb = smem4 + RAYS;                              // [RAYS] 1/direction | closest hit so far (float bits)
+    uint32_t* s_nq = (uint32_t*)(smem4 + 2u * RAYS);          // node items
+    uint32_t* s_lq = s_nq + K1_NQ;                            // leaf items
+    uint32_t* s_aq = s_lq + K1_LQ;                            // MASK candidates: ray << SH | triangle
+
+    const int rayCount = fp.rayCount;                         // :252
     const int lane = threadIdx.x;
     const int W = fp.W, H = fp.H;
     const Img16 depth{depthP, W, H}, histPrev{histPrevP, W, H};
-    const QSliceLayout lay = q_slice_layout(rayCount);
-    float4* slice = rayBuf + (size_t)blockIdx.x * lay.total_f4;
-    uint32_t* retry_list = (uint32_t*)(slice + lay.rays_f4);
+    const QSliceLayout lay = q_slice_layout(RB);
+    float4* g_dir = rayBuf + (size_t)blockIdx.x * lay.total_f4;          // [RAYS] direction | tMin as generated
+    uint32_t* retry_list = (uint32_t*)(g_dir + lay.dir_f4);
+    uint32_t* g_nq = (uint32_t*)(g_dir + lay.dir_f4 + lay.retry_f4);
+    uint32_t* g_lq = g_nq + K1_GNQ;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const char* node_base = (const char*)sc.nodes;
     const char* tri_base = (const char*)sc.tris;
     TraceCounters cnt{0, 0, 0, 0};
-    uint32_t nrays = 0;
+    uint32_t nrays = 0, nspill = 0;
+    // pixels per item P (a power of two), G = 64 / P lanes per pixel: lane = g * P + p generates rays g, g + G, ...
+    const int P = q_item_pixels(RB, rayCount), G = 64 / P;
+    const int plane = lane & (P - 1), grp = lane / P;
+    const uint32_t items_per_block = 64u / (uint32_t)P;       // an 8x8 pixel block is cut into 64 / P items
+    // STATS build only: shader cycles (s_memtime) per phase of this wave, summed over waves into stats[8..]
+    uint32_t ph_prev = STATS ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
+    uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // setup+raygen, inject/refill, node, leaf, alpha, retry list, resolve, item pull
+    uint32_t ph_n[4] = {0, 0, 0, 0};             // node steps / leaf steps / alpha steps / node items
+#define VKR_STAMP(K) { if (STATS) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph[K] += now_ - ph_prev; ph_prev = now_; } }
 
+    uint32_t chunk_next = 0, chunk_end = 0;
     for (;;) {
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(tile_counter, 1u);
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-        if (tile >= n_tiles) break;          // every wave reaches this: the counter only grows
-        constexpr bool HALF = (K1_TILE_PX == 32);
-        const int plane = HALF ? (lane & 31) : lane;          // pixel of the item this lane works on
-        const int half = HALF ? (lane >> 5) : 0;              // which rays it generates (i = half, half + 2, ...)
-        const int trow = (int)(tile / tiles_x);
-        const int px = (int)(tile % tiles_x) * 8 + (plane & 7);
-        const int py = HALF ? y0 + (trow >> 1) * 8 * fp.stripeMul + (trow & 1) * 4 + (plane >> 3)
-                            : y0 + trow * 8 * fp.stripeMul + (plane >> 3);
+        // items are pulled K1_CHUNK at a time: consecutive items are neighbouring pixel blocks, and a wave that walks them
+        // one after the other finds most of their nodes and triangles still in its CU's L1
+        if (chunk_next == chunk_end) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(tile_counter, (uint32_t)K1_CHUNK);
+            chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            chunk_end = chunk_next + (uint32_t)K1_CHUNK;
+        }
+        const uint32_t item = chunk_next++;
+        if (item >= n_items) break;          // every wave reaches this: the counter only grows
+        VKR_STAMP(7)
+        const uint32_t r_ = item / tiles_x;                                   // row of items: 8-row stripe * sub-block
+        const uint32_t sub = r_ % items_per_block, trow = r_ / items_per_block;
+        const uint32_t idx = sub * (uint32_t)P + (uint32_t)plane;             // pixel of the 8x8 block, row-major
+        const int px = (int)(item % tiles_x) * 8 + (int)(idx & 7u);
+        const int py = y0 + (int)trow * 8 * fp.stripeMul + (int)(idx >> 3);
 
         // ------------------------------------------------------------------ phase 1: per pixel
         PixelCtx pc;
         pc.valid = false;
-        pc.radius = 0.0f;
+        pc.radius = 0.0f; pc.viewZ = 0.0f; pc.worldPos = v3(0, 0, 0);
         if (px < W && py < y1) setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);   // :233-235
         const bool valid = pc.valid;
-        const float radius = pc.radius;
-        const unsigned long long vmask = HALF ? (__ballot(valid) & 0xffffffffull) : __ballot(valid);
+        const float radius = pc.radius, viewZ = pc.viewZ;     // kept across the queue loop for the resolve: 5 VGPRs
+        const V3 worldPos = pc.worldPos;
+        const unsigned long long pmask = (P == 64) ? ~0ull : ((1ull << P) - 1ull);
+        const unsigned long long vmask = __ballot(valid) & pmask;
         const uint32_t nvalid = (uint32_t)__popcll(vmask);
-        if (nvalid == 0) continue;   // wave-uniform: nothing to trace, nothing to resolve
-        const uint32_t rank = (uint32_t)__popcll(vmask & (HALF ? ((1ull << plane) - 1ull) : lt_mask));
-        const bool owner = valid && half == 0;                // the lane that resolves the pixel
+        if (nvalid == 0) { VKR_STAMP(0) continue; }   // wave-uniform: nothing to trace, nothing to resolve
+        const uint32_t rank = (uint32_t)__popcll(vmask & ((1ull << plane) - 1ull));
+        const bool owner = valid && grp == 0;                 // the lane that resolves the pixel
         if (valid) {
-            for (int i = half; i < rayCount; i += (HALF ? 2 : 1)) {                 // :403-430
+            for (int i = grp; i < rayCount; i += G) {                               // :403-430
                 V3 rayOrigin, rayDir;
                 float tMinRay;
                 make_ray(pc, rayCount, i, &rayOrigin, &rayDir, &tMinRay);
                 const uint32_t k = (uint32_t)i * nvalid + rank;
-                slice[(size_t)k * 3u] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
-                slice[(size_t)k * 3u + 1u] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
-                slice[(size_t)k * 3u + 2u] = make_float4(safe_rcp(rayDir.x), safe_rcp(rayDir.y), safe_rcp(rayDir.z), 0.0f);
-                s_tbest[k] = f2u(pc.radius);                                        // tMax = radius (:430)
+                s_ra[k] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
+                s_rb[k] = make_float4(safe_rcp(rayDir.x), safe_rcp(rayDir.y), safe_rcp(rayDir.z), pc.radius);   // tMax = radius (:430)
+                g_dir[k] = make_float4(rayDir.x, rayDir.y, rayDir.z, tMinRay);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        VKR_STAMP(0)
 
         // ------------------------------------------------------------------ phase 2: queues
         const uint32_t total = nvalid * (uint32_t)rayCount;
@@ -641,178 +698,248 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
         for (int round = 0; round < 2; ++round) {
             const uint32_t set_size = (round == 0) ? total : nretry;
             if (set_size == 0) break;
-            uint32_t next = 0, nq = 0, lq = 0, aq = 0;      // wave-uniform
+            uint32_t next = 0, nq = 0, lq = 0, aq = 0, gnq = 0, glq = 0;      // wave-uniform
             // ---------------- alpha step: MASK candidates (:163-173), n items from s_aq[base..]
             auto alpha_step = [&](uint32_t n, uint32_t base) {
                 if ((uint32_t)lane < n) {
-                    const uint32_t tri = s_aq[base + (uint32_t)lane], ray = (uint32_t)s_aqr[base + (uint32_t)lane];
-                    const float4 a = slice[(size_t)ray * 3u], b = slice[(size_t)ray * 3u + 1u];
+                    const uint32_t it = s_aq[base + (uint32_t)lane];
+                    const uint32_t tri = it & PMASK, ray = it >> SH;
+                    const float4 a = s_ra[ray], d = g_dir[ray];
                     const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
                     const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
-                    V3 ro = V3{a.x, a.y, a.z}, rdir = V3{b.x, b.y, b.z};
-                    float tmin = a.w;
-                    if (round) {
-                        const float adv = gmax(a.w * 2.0f, 2e-4f);
-                        ro = ro + rdir * adv;
-                        tmin = gmax(a.w, 1e-4f);
-                    }
                     float u, v, t;
-                    const float tbest = u2f(s_tbest[ray]);
-                    if (tri_hit(ro, rdir, ta, tb4, tc, tmin, tbest, &u, &v, &t) &&
+                    const float tbest = s_rb[ray].w;
+                    if (tri_hit(V3{a.x, a.y, a.z}, V3{d.x, d.y, d.z}, ta, tb4, tc, a.w, tbest, &u, &v, &t) &&
                         alpha_test(sc, f2u(ta.w) & 0x0fffffffu, f2u(tb4.w), u, v))
-                        atomicMin(&s_tbest[ray], f2u(t));
+                        atomicMin((uint32_t*)&s_rb[ray].w, f2u(t));
                 }
             };
+            // ---------------- queue loop.  Common path per iteration: one compare for "leaf step?", one for "node queue
+            // needs attention?", then a step.  Refills from the wave's global overflow stack and the throttled step width
+            // are the rare paths.
             for (;;) {
-                const bool no_more = (next >= set_size);
-                if (aq > 0u && lq < 64u && nq == 0u && no_more) { alpha_step(aq, 0u); aq = 0u; continue; }
-                if (lq >= 64u || (lq > 0u && nq == 0u && no_more)) {
+                bool do_leaf = lq >= 64u;
+                if (!do_leaf && (nq < K1_STEP || (glq | gnq) != 0u)) {
+                    if (glq > 0u) {
+                        // ---------------- leaf items back from the global stack (before anything else pushes leaves)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        uint32_t m = (uint32_t)K1_LQ - lq;
+                        if (m > glq) m = glq;
+                        glq -= m;
+                        for (uint32_t j = (uint32_t)lane; j < m; j += 64u) s_lq[lq + j] = g_lq[glq + j];
+                        lq += m;
+                        continue;
+                    }
+                    if (gnq > 0u) {
+                        // ---------------- node items back from the global stack
+                        if (nq < K1_STEP) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            uint32_t m = 2u * K1_STEP;
+                            if (m > gnq) m = gnq;
+                            if (m > (uint32_t)K1_NQ - nq) m = (uint32_t)K1_NQ - nq;
+                            gnq -= m;
+                            for (uint32_t j = (uint32_t)lane; j < m; j += 64u) s_nq[nq + j] = g_nq[gnq + j];
+                            nq += m;
+                        }
+                    } else if (next < set_size) {
+                        // ---------------- inject the next rays at the root
+                        uint32_t m = set_size - next;
+                        if (m > K1_STEP) m = K1_STEP;
+                        if (m > (uint32_t)K1_NQ - nq) m = (uint32_t)K1_NQ - nq;
+                        for (uint32_t j = (uint32_t)lane; j < m; j += 64u) {
+                            const uint32_t ray = round ? retry_list[next + j] : next + j;
+                            s_nq[nq + j] = ray << SH;   // root = node 0
+                            if (STATS) nrays++;
+                        }
+                        nq += m; next += m;
+                    }
+                    VKR_STAMP(1)
+                    if (nq == 0u) {                     // nothing left to descend: drain the leaves, then the MASK candidates
+                        if (lq > 0u) do_leaf = true;
+                        else if (aq > 0u) { alpha_step(aq, 0u); aq = 0u; if (STATS) ph_n[2]++; VKR_STAMP(4) continue; }
+                        else break;
+                    }
+                }
+                if (do_leaf) {
                     // ---------------- leaf step: queryAoClosestHit's candidate loop (:125-182) for <= 64 leaves
                     const uint32_t n = lq < 64u ? lq : 64u;
                     lq -= n;
-                    uint32_t cntT = 0;
-                    uint2 it = make_uint2(0u, 0u);
-                    if ((uint32_t)lane < n) it = make_uint2(s_lq[lq + (uint32_t)lane], (uint32_t)s_lqr[lq + (uint32_t)lane]);
-                    float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 1, 0);
-                    uint32_t first = 0;
-                    float tbest0 = 0.0f;
-                    if ((uint32_t)lane < n) {
-                        a = slice[(size_t)it.y * 3u]; b = slice[(size_t)it.y * 3u + 1u];
-                        const uint32_t x = ~it.x;
-                        first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
-                        tbest0 = u2f(s_tbest[it.y]);
+                    const bool act = (uint32_t)lane < n;
+                    const uint32_t it = act ? s_lq[lq + (uint32_t)lane] : 0u;      // item 0: ray 0, triangle 0 (valid addresses)
+                    const uint32_t ray = it >> SH, pl = it & PMASK;
+                    const uint32_t cntT = act ? (pl & 1u) + 1u : 0u;
+                    const uint32_t toff = (pl & ~1u) * 24u;                        // first triangle * 48 bytes
+                    const float4 a = s_ra[ray], d = g_dir[ray];
+                    const float tbest0 = s_rb[ray].w;
+                    const float4* tp = (const float4*)(tri_base + toff);
+                    const float4 ta0 = tp[0], tb0 = tp[1], tc0 = tp[2];
+                    const unsigned long long m2 = __ballot(cntT > 1u);
+                    float4 ta1 = ta0, tb1 = tb0, tc1 = tc0;
+                    if (m2 != 0ull) {                                               // wave-uniform
+                        const float4* tq = tp + ((cntT > 1u) ? 3 : 0);
+                        ta1 = tq[0]; tb1 = tq[1]; tc1 = tq[2];
                     }
-                    V3 ro = V3{a.x, a.y, a.z}, rdir = V3{b.x, b.y, b.z};
-                    float tmin = a.w;
-                    if (round) {                                                    // :193-197
-                        const float adv = gmax(a.w * 2.0f, 2e-4f);
-                        ro = ro + rdir * adv;
-                        tmin = gmax(a.w, 1e-4f);
-                    }
+                    const V3 ro = V3{a.x, a.y, a.z}, rdir = V3{d.x, d.y, d.z};
+                    const float tmin = a.w;
                     float tbest = tbest0;
-                    for (uint32_t j = 0; j < (uint32_t)VKR_LEAF_MAX; ++j) {
-                        const unsigned long long am = __ballot(j < cntT);
-                        if (am == 0ull) break;
-                        bool cand = false;   // MASK candidate: geometric hit that still needs the alpha test
-                        if (j < cntT) {
-                            const float4* tp = (const float4*)(tri_base + (size_t)(first + j) * 48u);
-                            float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
-                            if (STATS) { cnt.tris++; if ((int)(__ffsll((long long)am) - 1) == lane) cnt.wave_tri_iters++; }
-                            float u, v, t;
-                            const bool geo = tri_hit(ro, rdir, ta, tb4, tc, tmin, tbest, &u, &v, &t);
-                            const uint32_t cls = f2u(ta.w) >> 28;                   // candidate filter :142-173
-                            if (geo && cls == 0u) tbest = t;
-                            cand = geo && cls == 2u;
-                        }
-                        // alpha tests are not run here at one or two lanes' width: candidates queue up and are tested
-                        // a wave at a time (accepting a hit later only delays pruning; the minimum is the same)
-                        const unsigned long long cm = __ballot(cand);
-                        if (cm != 0ull) {
-                            if (cand) { const uint32_t ix = aq + mbcnt64(cm); s_aq[ix] = first + j; s_aqr[ix] = (uint16_t)it.y; }
-                            aq += (uint32_t)__popcll(cm);
-                            if (aq >= 64u) { aq -= 64u; alpha_step(64u, aq); }
-                        }
-                    }
-                    if (tbest < tbest0) atomicMin(&s_tbest[it.y], f2u(tbest));      // t > tmin >= 0: bits order like floats
+#define VKR_LEAF_TRI(J, TA, TB, TC, AM)                                                                             \
+    {                                                                                                               \
+        bool cand = false;   /* MASK candidate: geometric hit that still needs the alpha test */                    \
+        if ((uint32_t)(J) < cntT) {                                                                                 \
+            if (STATS) { cnt.tris++; if ((int)(__ffsll((long long)(AM)) - 1) == lane) cnt.wave_tri_iters++; }       \
+            float u, v, t;                                                                                          \
+            const bool geo = tri_hit(ro, rdir, TA, TB, TC, tmin, tbest, &u, &v, &t);                                \
+            const uint32_t cls = f2u(TA.w) >> 28;                   /* candidate filter :142-173 */                 \
+            if (geo && cls == 0u) tbest = t;                                                                        \
+            cand = geo && cls == 2u;                                                                                \
+        }                                                                                                           \
+        /* alpha tests are not run here at one or two lanes' width: candidates queue up and are tested a wave at */ \
+        /* a time (accepting a hit later only delays pruning; the minimum is the same) */                           \
+        const unsigned long long cm = __ballot(cand);                                                               \
+        if (cm != 0ull) {                                                                                           \
+            if (cand) s_aq[aq + mbcnt64(cm)] = (ray << SH) | ((pl >> 1) + (uint32_t)(J));                           \
+            aq += (uint32_t)__popcll(cm);                                                                           \
+            if (aq >= 64u) { aq -= 64u; VKR_STAMP(3) alpha_step(64u, aq); if (STATS) ph_n[2]++; VKR_STAMP(4) }      \
+        }                                                                                                           \
+    }
+                    VKR_LEAF_TRI(0, ta0, tb0, tc0, __ballot(act))
+                    if (m2 != 0ull) VKR_LEAF_TRI(1, ta1, tb1, tc1, m2)
+#undef VKR_LEAF_TRI
+                    if (tbest < tbest0) atomicMin((uint32_t*)&s_rb[ray].w, f2u(tbest));   // t > tmin >= 0: bits order like floats
+                    if (STATS) ph_n[1]++;
+                    VKR_STAMP(3)
                     continue;
                 }
-                if (nq < 64u && next < set_size) {
-                    // ---------------- inject the next rays at the root
-                    const uint32_t m = (set_size - next) < 64u ? (set_size - next) : 64u;
-                    if ((uint32_t)lane < m) {
-                        const uint32_t ray = round ? retry_list[next + (uint32_t)lane] : next + (uint32_t)lane;
-                        s_nq[nq + (uint32_t)lane] = ray << KQ_NODE_BITS;   // root = node 0
-                    }
-                    nq += m; next += m;
-                    if (STATS) { if ((uint32_t)lane < m) nrays++; }
-                }
-                if (nq == 0u) break;
-                // ---------------- node step: pops n, pushes <= 4n node items (and <= 4n leaf items, lq < 64 here)
-                uint32_t n = nq < 64u ? nq : 64u;
-                {
-                    const uint32_t room = (uint32_t)K1_NQ - KQ_GUARD - (nq < (uint32_t)K1_NQ - KQ_GUARD ? nq : (uint32_t)K1_NQ - KQ_GUARD);
-                    const uint32_t fit = room / 3u;
+                // ---------------- node step: pops n <= K1_STEP items, pushes <= 4n node items and <= 4n leaf items.
+                // Pushes go to LDS while they fit and to the wave's global stack beyond that (rare); the step is narrowed
+                // only when LDS + global capacity could run out: n shrinks down to one item per step = strict depth-first,
+                // whose growth is bounded by 3 x tree depth (KQ_GUARD).
+                uint32_t n = nq < K1_STEP ? nq : K1_STEP;
+                if (nq + gnq + 3u * K1_STEP > (uint32_t)K1_NQ + K1_GNQ - KQ_GUARD) {            // rare
+                    const uint32_t cap = (uint32_t)K1_NQ + K1_GNQ - KQ_GUARD, used = nq + gnq;
+                    const uint32_t fit = (cap > used ? cap - used : 0u) / 3u;
                     if (n > fit) n = fit ? fit : 1u;
                 }
                 nq -= n;
                 // Every lane runs the step; lanes without an item work on item 0 (ray 0 at the root: valid addresses, no
-                // side effects) and are masked out of the hit tests.  Keeping the step in one basic block lets the hit /
-                // leaf ballots come straight out of the compares (v_cmp -> SGPR pair) instead of being re-materialised
-                // from booleans carried across a divergent region: -16 VALU instructions per step.
-                const bool act = (uint32_t)lane < n;
-                const uint32_t item = act ? s_nq[nq + (uint32_t)lane] : 0u;
-                const uint32_t ray = item >> KQ_NODE_BITS;
-                const uint32_t node = item & ((1u << KQ_NODE_BITS) - 1u);
-                const float4 a = slice[(size_t)ray * 3u], ir = slice[(size_t)ray * 3u + 2u];
-                const float4* np = (const float4*)(node_base + ((size_t)node << 6));
-                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                // padded: culling may only err towards extra visits; lanes without an item get an exit distance below any
-                // entry distance (tn >= tmin > 0), so none of their four tests can pass
-                const float tb = act ? u2f(s_tbest[ray]) * 1.000001f : -3.0e38f;
-                if (STATS) { if (act) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.wave_node_iters++; } }
-                V3 ro = V3{a.x, a.y, a.z};
-                float tmin = a.w;
-                if (round) {
-                    const float4 b = slice[(size_t)ray * 3u + 1u];
-                    const float adv = gmax(a.w * 2.0f, 2e-4f);
-                    ro = ro + V3{b.x, b.y, b.z} * adv;
-                    tmin = gmax(a.w, 1e-4f);
-                }
-                const V3 id = V3{ir.x, ir.y, ir.z};
-                // Slab tests straight on the quantised planes (see k_trace): t = fma(q, s*id, (o - ro)*id)
-                const uint32_t eb = f2u(q0.w);
-                const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
-                            az = u2f(((eb >> 16) & 0xffu) << 23) * id.z;
-                const float bx = (q0.x - ro.x) * id.x, by = (q0.y - ro.y) * id.y, bz = (q0.z - ro.z) * id.z;
-                const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
-                const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
-                const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
-                const uint32_t r0 = f2u(q3.x), r1 = f2u(q3.y), r2 = f2u(q3.z), r3 = f2u(q3.w);
-                // two children per packed fma (v_pk_fma_f32 rounds each half like the scalar fma)
+                // side effects) and are masked out of the hit tests by an exit distance below any entry distance.
+                auto fetch = [&](uint32_t it) -> NodeIn {
+                    NodeIn in;
+                    const uint32_t ray = it >> SH, node = it & PMASK;
+                    const float4* np = (const float4*)(node_base + ((size_t)node << 6));
+                    in.q0 = np[0]; in.q1 = np[1]; in.q2 = np[2]; in.q3 = np[3];
+                    in.a = s_ra[ray]; in.b = s_rb[ray];
+                    in.rayhi = it & ~PMASK;
+                    return in;
+                };
+                auto process = [&](const NodeIn& in, bool act) {
+                    const float4 q0 = in.q0, q1 = in.q1, q2 = in.q2, q3 = in.q3;
+                    // padded: culling may only err towards extra visits; lanes without an item get an exit distance below
+                    // any entry distance (tn >= tmin > 0), so none of their four tests can pass
+                    const float tb = act ? in.b.w * 1.000001f : -3.0e38f;
+                    if (STATS) { if (act) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(act)) - 1) == lane) cnt.wave_node_iters++; } }
+                    const float tmin = in.a.w;
+                    const V3 id = V3{in.b.x, in.b.y, in.b.z};
+                    // Slab tests straight on the quantised planes: plane = fma(q, s, o), t = (plane - ro) * id is evaluated
+                    // as fma(q, s*id, (o - ro)*id): one fma per plane.  The direction sign picks the near/far byte quads
+                    // once per axis; unused slots are stored inverted and miss by themselves.  Rounding of this form is
+                    // covered by the leaf padding (bvh_build.hip tri_box) and by the outward quantisation.
+                    const float ax = q2.z * id.x, ay = q2.w * id.y, az = q0.w * id.z;
+                    const float bx = (q0.x - in.a.x) * id.x, by = (q0.y - in.a.y) * id.y, bz = (q0.z - in.a.z) * id.z;
+                    const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
+                    const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
+                    const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
+                    const uint32_t r0 = f2u(q3.x), r1 = f2u(q3.y), r2 = f2u(q3.z), r3 = f2u(q3.w);
+                    // two children per packed fma (v_pk_fma_f32 rounds each half like the scalar fma)
 #define VKR_PLANES(W, A, B, P01, P23)                                                                               \
     const f2v P01 = pk_fma(f2v{ubyte_f(W, 0), ubyte_f(W, 1)}, A, B), P23 = pk_fma(f2v{ubyte_f(W, 2), ubyte_f(W, 3)}, A, B);
-                VKR_PLANES(nx4, ax, bx, nx01, nx23) VKR_PLANES(ny4, ay, by, ny01, ny23) VKR_PLANES(nz4, az, bz, nz01, nz23)
-                VKR_PLANES(fx4, ax, bx, fx01, fx23) VKR_PLANES(fy4, ay, by, fy01, fy23) VKR_PLANES(fz4, az, bz, fz01, fz23)
+                    VKR_PLANES(nx4, ax, bx, nx01, nx23) VKR_PLANES(ny4, ay, by, ny01, ny23) VKR_PLANES(nz4, az, bz, nz01, nz23)
+                    VKR_PLANES(fx4, ax, bx, fx01, fx23) VKR_PLANES(fy4, ay, by, fy01, fy23) VKR_PLANES(fz4, az, bz, fz01, fz23)
 #undef VKR_PLANES
-                // a NaN entry distance fails the comparison, like the k != 0xffffffff test of the keyed form did
-#define VKR_SLABQ(H, NX, NY, NZ, FX, FY, FZ)                                                                        \
-    const bool H = __builtin_fmaxf(__builtin_fmaxf(NX, NY), __builtin_fmaxf(NZ, tmin)) <=                           \
-                   __builtin_fminf(__builtin_fminf(FX, FY), __builtin_fminf(FZ, tb));
-                VKR_SLABQ(h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)
-                VKR_SLABQ(h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)
-                VKR_SLABQ(h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)
-                VKR_SLABQ(h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
+                    // a NaN entry distance fails the comparison
+#define VKR_SLABQ(H, NX, NY, NZ, FX, FY, FZ) const bool H = vmax2(vmax3(NX, NY, NZ), tmin) <= vmin2(vmin3(FX, FY, FZ), tb);
+                    VKR_SLABQ(h0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)
+                    VKR_SLABQ(h1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)
+                    VKR_SLABQ(h2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)
+                    VKR_SLABQ(h3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
 #undef VKR_SLABQ
-                // append the hit children: internal nodes to the node queue, leaves to the leaf queue, slot by slot
-                // (measured: sorting them near-to-far first saves 1 % of the visits and costs more than that; one
-                // lane-major prefix sum instead of per-slot ballots makes a ray's siblings pop together and costs 9 %)
-#define VKR_APPEND(HC, RC)                                                                                          \
+                    // append the hit children: internal nodes to the node queue, leaves to the leaf queue, slot by slot
+                    // (measured in round 1: sorting them near-to-far first saves 1 % of the visits and costs more than that;
+                    // one lane-major prefix sum instead of per-slot ballots makes a ray's siblings pop together and costs 9 %)
+                    const uint32_t rayhi = in.rayhi, rayhi_leaf = in.rayhi + 0x80000000u;   // + leaf reference: bit 31 cancels
+                    const bool l0 = (int)r0 < 0, l1 = (int)r1 < 0, l2 = (int)r2 < 0, l3 = (int)r3 < 0;
+                    const unsigned long long hm0 = __ballot(h0), hm1 = __ballot(h1), hm2 = __ballot(h2), hm3 = __ballot(h3);
+                    const unsigned long long lm0 = __ballot(l0), lm1 = __ballot(l1), lm2 = __ballot(l2), lm3 = __ballot(l3);
+                    const unsigned long long mn0 = hm0 & ~lm0, mn1 = hm1 & ~lm1, mn2 = hm2 & ~lm2, mn3 = hm3 & ~lm3;
+                    const unsigned long long ml0 = hm0 & lm0, ml1 = hm1 & lm1, ml2 = hm2 & lm2, ml3 = hm3 & lm3;
+                    const uint32_t cn0 = (uint32_t)__popcll(mn0), cn1 = (uint32_t)__popcll(mn1), cn2 = (uint32_t)__popcll(mn2), cn3 = (uint32_t)__popcll(mn3);
+                    const uint32_t cl0 = (uint32_t)__popcll(ml0), cl1 = (uint32_t)__popcll(ml1), cl2 = (uint32_t)__popcll(ml2), cl3 = (uint32_t)__popcll(ml3);
+                    const uint32_t totn = (cn0 + cn1) + (cn2 + cn3), totl = (cl0 + cl1) + (cl2 + cl3);
+                    if (nq + totn <= (uint32_t)K1_NQ && lq + totl <= (uint32_t)K1_LQ) {
+                        // everything fits in LDS (the common case): eight predicated stores, no further checks
+                        if (h0 && !l0) s_nq[nq + mbcnt64(mn0)] = rayhi | r0;
+                        if (h0 && l0) s_lq[lq + mbcnt64(ml0)] = rayhi_leaf + r0;
+                        if (h1 && !l1) s_nq[nq + cn0 + mbcnt64(mn1)] = rayhi | r1;
+                        if (h1 && l1) s_lq[lq + cl0 + mbcnt64(ml1)] = rayhi_leaf + r1;
+                        if (h2 && !l2) s_nq[nq + (cn0 + cn1) + mbcnt64(mn2)] = rayhi | r2;
+                        if (h2 && l2) s_lq[lq + (cl0 + cl1) + mbcnt64(ml2)] = rayhi_leaf + r2;
+                        if (h3 && !l3) s_nq[nq + (totn - cn3) + mbcnt64(mn3)] = rayhi | r3;
+                        if (h3 && l3) s_lq[lq + (totl - cl3) + mbcnt64(ml3)] = rayhi_leaf + r3;
+                        nq += totn; lq += totl;
+                    } else {
+                        // rare: per slot, LDS while it fits, the wave's global stack beyond
+#define VKR_PUSH(SQ, QN, CAP, GQ, GN, PRED, MASK, PC, ITEM)                                                         \
     {                                                                                                               \
-        const unsigned long long hm = __ballot(HC), lm = __ballot((int)RC < 0);                                     \
-        const unsigned long long mn = hm & ~lm, ml = hm & lm;                                                       \
-        if (HC) {                                                                                                   \
-            if ((int)RC < 0) { const uint32_t ix = lq + mbcnt64(ml); s_lq[ix] = RC; s_lqr[ix] = (uint16_t)ray; }    \
-            else s_nq[nq + mbcnt64(mn)] = (ray << KQ_NODE_BITS) | RC;                                               \
-        }                                                                                                           \
-        nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
+        if (QN + (PC) <= (uint32_t)(CAP)) { if (PRED) SQ[QN + mbcnt64(MASK)] = (ITEM); QN += (PC); }                \
+        else { if (PRED) GQ[GN + mbcnt64(MASK)] = (ITEM); GN += (PC); if (STATS) nspill += (lane == 0) ? (PC) : 0u; } \
     }
-                VKR_APPEND(h0, r0) VKR_APPEND(h1, r1) VKR_APPEND(h2, r2) VKR_APPEND(h3, r3)
-#undef VKR_APPEND
+                        VKR_PUSH(s_nq, nq, K1_NQ, g_nq, gnq, h0 && !l0, mn0, cn0, rayhi | r0)
+                        VKR_PUSH(s_lq, lq, K1_LQ, g_lq, glq, h0 && l0, ml0, cl0, rayhi_leaf + r0)
+                        VKR_PUSH(s_nq, nq, K1_NQ, g_nq, gnq, h1 && !l1, mn1, cn1, rayhi | r1)
+                        VKR_PUSH(s_lq, lq, K1_LQ, g_lq, glq, h1 && l1, ml1, cl1, rayhi_leaf + r1)
+                        VKR_PUSH(s_nq, nq, K1_NQ, g_nq, gnq, h2 && !l2, mn2, cn2, rayhi | r2)
+                        VKR_PUSH(s_lq, lq, K1_LQ, g_lq, glq, h2 && l2, ml2, cl2, rayhi_leaf + r2)
+                        VKR_PUSH(s_nq, nq, K1_NQ, g_nq, gnq, h3 && !l3, mn3, cn3, rayhi | r3)
+                        VKR_PUSH(s_lq, lq, K1_LQ, g_lq, glq, h3 && l3, ml3, cl3, rayhi_leaf + r3)
+#undef VKR_PUSH
+                    }
+                };
+                const bool act0 = (uint32_t)lane < n, act1 = (uint32_t)lane + 64u < n;
+                const uint32_t it0 = act0 ? s_nq[nq + (uint32_t)lane] : 0u;
+                const NodeIn in0 = fetch(it0);
+                if (K1_STEP > 64u && n > 64u) {                                     // wave-uniform
+                    const uint32_t it1 = act1 ? s_nq[nq + 64u + (uint32_t)lane] : 0u;
+                    const NodeIn in1 = fetch(it1);
+                    process(in0, act0);
+                    process(in1, act1);
+                } else {
+                    process(in0, act0);
+                }
+                if (STATS) { ph_n[0]++; ph_n[3] += n; }
+                VKR_STAMP(2)
             }
             if (round == 0) {
-                // rays that ended on a self-hit are traced once more from an advanced origin (:193-200)
+                // rays that ended on a self-hit are traced once more from an advanced origin (:193-200): their LDS records
+                // are rewritten in place (the values every step of round 1 would otherwise recompute)
                 for (int i = 0; i < rayCount; ++i) {
                     bool need = false;
                     const uint32_t k = (uint32_t)i * nvalid + rank;
+                    float4 a = make_float4(0, 0, 0, 0);
                     if (owner) {
-                        const float tbv = u2f(s_tbest[k]);
-                        const float tmin0 = slice[(size_t)k * 3u].w;
-                        need = (tbv < radius) && (tbv <= tmin0 * 1.5f);
+                        a = s_ra[k];
+                        const float tbv = s_rb[k].w;
+                        need = (tbv < radius) && (tbv <= a.w * 1.5f);
                     }
                     const unsigned long long m = __ballot(need);
                     if (need) {
                         retry_list[nretry + mbcnt64(m)] = k;
-                        s_tbest[k] = f2u(radius);
+                        const float4 d = g_dir[k];
+                        const float adv = gmax(a.w * 2.0f, 2e-4f);                  // :194-196
+                        const V3 ro = V3{a.x, a.y, a.z} + V3{d.x, d.y, d.z} * adv;
+                        s_ra[k] = make_float4(ro.x, ro.y, ro.z, gmax(a.w, 1e-4f));
+                        s_rb[k].w = radius;
                         retry_mask |= 1u << i;
                     }
                     nretry += (uint32_t)__popcll(m);
@@ -823,6 +950,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
                 }
             }
         }
+        VKR_STAMP(5)
 
         // ------------------------------------------------------------------ phase 3: per pixel resolve + temporal
         if (owner) {
@@ -830,8 +958,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
             uint32_t mask = 0;
             for (int i = 0; i < rayCount; ++i) {                                    // :431 in ray order
                 const uint32_t k = (uint32_t)i * nvalid + rank;
-                const float tbv = u2f(s_tbest[k]);
-                const float tmin0 = slice[(size_t)k * 3u].w;
+                const float tbv = s_rb[k].w;
+                const float tmin0 = g_dir[k].w;
                 const float tmax = radius;
                 float vis = 1.0f;
                 if (tbv < tmax) {                                                   // a hit was committed
@@ -846,20 +974,64 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(VKR_Q_
                 }
                 visibility += vis;
             }
-            // the pixel context is rebuilt rather than kept in registers across the queue loop (it is ~25 VGPRs, and
-            // the loop's occupancy matters more than ~500 instructions per pixel): same inputs, same values
-            PixelCtx pc2;
-            setup_pixel(fp, depth, histCurr, hitMask, px, py, pc2);
+            PixelCtx pc2;                     // resolve_pixel reads viewZ and worldPos only
+            pc2.viewZ = viewZ; pc2.worldPos = worldPos;
             resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc2, visibility, mask);
         }
+        VKR_STAMP(6)
     }
+#undef VKR_STAMP
     if (STATS) {
+        if (lane == 0) {
+            for (int k = 0; k < 8; ++k) atomicAdd(&stats[8 + k], (unsigned long long)ph[k]);
+            for (int k = 0; k < 4; ++k) atomicAdd(&stats[16 + k], (unsigned long long)ph_n[k]);
+            atomicAdd(&stats[20], 1ull);
+            atomicAdd(&stats[5], (unsigned long long)nspill);
+        }
         atomicAdd(&stats[0], (unsigned long long)nrays);
         atomicAdd(&stats[1], (unsigned long long)cnt.nodes);
         atomicAdd(&stats[2], (unsigned long long)cnt.tris);
         atomicAdd(&stats[3], (unsigned long long)cnt.wave_node_iters);
         atomicAdd(&stats[4], (unsigned long long)cnt.wave_tri_iters);
     }
+}
+
+// ray bits of the streaming kernel for this tree: 8 (256 rays per item) while triangle and node indices fit the item
+// payload, fewer for larger trees; 0 = the tree needs the one-ray-per-lane kernel
+static int q_ray_bits(const vkr_ctx* c)
+{
+    for (int rb = K1_RB; rb >= 6; --rb)
+        if ((uint64_t)c->tri_count * 2u <= (1ull << (32 - rb)) && (uint64_t)c->wide_count <= (1ull << (32 - rb))) {
+            if (const char* e = getenv("VKR_Q_RAY_BITS")) { int v = atoi(e); if (v >= 6 && v < rb) return v; }   // tests: force a narrower item
+            return rb;
+        }
+    return 0;
+}
+
+template <bool STATS, int RB>
+static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,
+                                 uint16_t* hist_curr, uint32_t* hit_mask, int y0, int y1, uint32_t tiles_x, uint32_t tiles_y, hipStream_t st)
+{
+    hipError_t e;
+    const uint32_t n_items = tiles_x * tiles_y * (64u / (uint32_t)q_item_pixels(RB, fp.rayCount));
+    // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
+    size_t lds = q_lds_bytes(RB);
+    if (const char* x = getenv("VKR_K1_EXTRA_LDS")) lds += (size_t)atoi(x);   // development: occupancy experiments
+    int per_cu = 0;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<STATS, RB>, K1_BLOCK, lds)) != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
+    if (blocks > n_items) blocks = n_items;
+    const size_t need = (size_t)blocks * q_slice_layout(RB).total_f4;
+    if (c->d_raybuf.n < need) {
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
+    }
+    if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(1)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
+    k_trace_q<STATS, RB><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, n_items,
+                                                        c->d_raybuf.p, c->d_tile_counter.p, STATS ? c->d_stats.p : nullptr);
+    return hipGetLastError();
 }
 
 hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,
@@ -869,34 +1041,20 @@ hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* 
     const uint32_t mul = fp.stripeMul > 1 ? (uint32_t)fp.stripeMul : 1u;
     uint32_t tiles_x = ((uint32_t)fp.W + 7u) / 8u, tiles_y = (((uint32_t)(y1 - y0) + 7u) / 8u + mul - 1u) / mul;
     uint32_t n_tiles = tiles_x * tiles_y;
-    const bool streaming = c->trace_streaming && c->wide_count <= (1u << KQ_NODE_BITS);
-    if (streaming && K1_TILE_PX == 32) n_tiles *= 2u;            // 8x4 items: two per 8x8 tile row (see k_trace_q)
+    const int rb = c->trace_streaming ? q_ray_bits(c) : 0;
     SceneDev sc = scene_dev(c);
     hipError_t e;
-    if (streaming) {
-        // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
-        const size_t lds = (size_t)fp.rayCount * (size_t)K1_TILE_PX * 4u + (size_t)K1_NQ * 4u + (size_t)KQ_LQ * 6u + (size_t)KQ_AQ * 6u;
-        int per_cu = 0;
-        if (c->stats_enabled) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<true>, K1_BLOCK, lds);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false>, K1_BLOCK, lds);
-        if (e != hipSuccess) return e;
-        if (per_cu < 1) per_cu = 1;
-        uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
-        if (blocks > n_tiles) blocks = n_tiles;
-        const size_t need = (size_t)blocks * q_slice_layout(fp.rayCount).total_f4;
-        if (c->d_raybuf.n < need) {
-            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-            if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
-        }
-        if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(1)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
-        if (c->stats_enabled)
-            k_trace_q<true><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
-                                                           n_tiles, c->d_raybuf.p, c->d_tile_counter.p, c->d_stats.p);
-        else
-            k_trace_q<false><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
-                                                            n_tiles, c->d_raybuf.p, c->d_tile_counter.p, nullptr);
-        return hipGetLastError();
+    if (rb != 0) {
+        const bool s = c->stats_enabled;
+#define VKR_Q(S, R) trace_q_launch<S, R>(c, sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, tiles_y, st)
+#if K1_RB >= 8
+        if (rb == 8) return s ? VKR_Q(true, 8) : VKR_Q(false, 8);
+#endif
+#if K1_RB >= 7
+        if (rb == 7) return s ? VKR_Q(true, 7) : VKR_Q(false, 7);
+#endif
+        return s ? VKR_Q(true, 6) : VKR_Q(false, 6);
+#undef VKR_Q
     }
     // ray buffer: one slice per wave of the launch, sized for the current rays/px (grow-only, so steady-state
     // frames allocate nothing)

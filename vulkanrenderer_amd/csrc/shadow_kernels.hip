@@ -414,8 +414,7 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
                         const uint32_t ref = s_lq[lq + (uint32_t)lane];
                         ray = (uint32_t)s_lqr[lq + (uint32_t)lane];
                         if (!((s_occ[ray >> 5] >> (ray & 31u)) & 1u)) {
-                            const uint32_t x = ~ref;
-                            first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
+                            first = leaf_ref_first(ref); cntT = leaf_ref_count(ref);
                             if (MODE == 0) {
                                 const float4 o = s_org[ray & 63u], d = s_dir[ray >> 6];
                                 ro = V3{o.x, o.y, o.z}; rdir = V3{d.x, d.y, d.z}; tmin = 0.001f; tmax = 500.0f;   // :203-204
@@ -480,9 +479,7 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
                         }
                         // Slab tests on the quantised planes as in k_trace_q; these rays are long, so the interval gets
                         // the relative padding of box_key() on top (rounding may only add visits)
-                        const uint32_t eb = f2u(q0.w);
-                        const float ax = u2f((eb & 0xffu) << 23) * id.x, ay = u2f(((eb >> 8) & 0xffu) << 23) * id.y,
-                                    az = u2f(((eb >> 16) & 0xffu) << 23) * id.z;
+                        const float ax = q2.z * id.x, ay = q2.w * id.y, az = q0.w * id.z;   // scales are stored as floats
                         const float bx = (q0.x - ro.x) * id.x, by = (q0.y - ro.y) * id.y, bz = (q0.z - ro.z) * id.z;
                         const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
                         const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
@@ -745,8 +742,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                     const uint32_t ref = s_lq[lq + (uint32_t)lane];
                     pix = (uint32_t)s_lqp[lq + (uint32_t)lane];
                     if ((s_mask[pix] & full) != full) {
-                        const uint32_t x = ~ref;
-                        first = x & 0x0fffffffu; cntT = ((x >> 28) & 7u) + 1u;
+                        first = leaf_ref_first(ref); cntT = leaf_ref_count(ref);
                         ro = V3{s_ox[pix], s_oy[pix], s_oz[pix]};
                     }
                 }
@@ -801,8 +797,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
             const float4* np = (const float4*)(node_base + ((size_t)node << 6));
             const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             const V3 o = V3{s_ox[pix], s_oy[pix], s_oz[pix]};
-            const uint32_t eb = f2u(q0.w);
-            const float sx = u2f((eb & 0xffu) << 23), sy = u2f(((eb >> 8) & 0xffu) << 23), sz = u2f(((eb >> 16) & 0xffu) << 23);
+            const float sx = q2.z, sy = q2.w, sz = q0.w;
             // plane - origin per axis: fma(q, s, node origin - ray origin)
             const float bx = q0.x - o.x, by = q0.y - o.y, bz = q0.z - o.z;
             const uint32_t nx4 = posx ? f2u(q1.x) : f2u(q1.w), fx4 = posx ? f2u(q1.w) : f2u(q1.x);

@@ -3,13 +3,15 @@
 // Data layout in HBM (16-byte aligned, read as dwordx4 quarters):
 //   wide node (64 B, up to 4 children, boxes quantised to 8 bits per plane in the frame of their union --
 //   traversal is bound by L1/TA bytes per visit, not by arithmetic, so 64 B beats 128 B of float planes):
-//       q0 origin.xyz | ex | ey<<8 | ez<<16 | nchild<<24        (scale_a = 2^(e_a-127) = bits e_a<<23)
+//       q0 origin.xyz | scale_z                  (scale_a = a power of two, stored as a float: no decode in the node step)
 //       q1 qminx[4] qminy[4] qminz[4] qmaxx[4]   (one byte per child, plane = fma(q, scale, origin))
-//       q2 qmaxy[4] qmaxz[4] 0 0
+//       q2 qmaxy[4] qmaxz[4] scale_x scale_y
 //       q3 child[4]
 //       child >= 0            : wide node index
-//       child <  0            : leaf, x = ~child: first triangle = x & 0x0fffffff, count = ((x >> 28) & 7) + 1
-//       unused slot           : child = 0x7fffffff (slots >= nchild are skipped)
+//       child <  0            : leaf: bit 31 set, bits 30..1 = first triangle, bit 0 = count - 1 (leaves hold 1 or 2
+//                               triangles).  The streaming kernels turn it into a queue item with ONE add:
+//                               item = ray << (32 - RB) | first << 1 | (count - 1)
+//       unused slot           : child = 0x7fffffff, planes stored inverted (qmin = 255, qmax = 0): fails every slab test
 //   tri (48 B, Morton order so a leaf's triangles are contiguous):
 //       q0 = v0.xyz (mesh | class<<28) | q1 = e1.xyz prim | q2 = e2.xyz flat_id
 //       class: 0 = always an occluder for AO, 1 = never (BLEND), 2 = alpha-test (MASK)
@@ -31,8 +33,13 @@ constexpr int VKR_GRAPH_MAX_DEPTH = 64;   // scene-graph depth accepted by vkr_h
 #ifndef VKR_LEAF_MAX_N
 #define VKR_LEAF_MAX_N 2
 #endif
-constexpr int VKR_LEAF_MAX = VKR_LEAF_MAX_N;      // triangles per leaf (encoding allows 8); measured 1/2/3/4/6: 2 is best for K1, 1-2 for the sun packets
+constexpr int VKR_LEAF_MAX = VKR_LEAF_MAX_N;      // triangles per leaf; measured 1/2/3/4/6: 2 is best for K1, 1-2 for the sun packets
+static_assert(VKR_LEAF_MAX >= 1 && VKR_LEAF_MAX <= 2, "the leaf reference has one bit for the triangle count");
 constexpr uint32_t VKR_CHILD_NONE = 0x7fffffffu;
+// leaf reference (see the layout above)
+__host__ __device__ inline uint32_t leaf_ref_make(uint32_t first, uint32_t count) { return 0x80000000u | (first << 1) | (count - 1u); }
+__host__ __device__ inline uint32_t leaf_ref_first(uint32_t ref) { return (ref & 0x7fffffffu) >> 1; }
+__host__ __device__ inline uint32_t leaf_ref_count(uint32_t ref) { return (ref & 1u) + 1u; }
 #ifndef VKR_LEAF_VOTE
 #define VKR_LEAF_VOTE 1   // K1 runs a triangle step when n_leaf * VKR_LEAF_VOTE >= n_node * VKR_LEAF_VOTE_DEN
 #endif
@@ -112,7 +119,6 @@ VKR_DI bool alpha_test(const SceneDev& sc, uint32_t mesh, uint32_t prim, float b
 struct NodeDec {
     float mnx[4], mny[4], mnz[4], mxx[4], mxy[4], mxz[4];
     uint32_t ref[4];
-    uint32_t nchild;
 };
 
 VKR_DI float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
@@ -120,9 +126,7 @@ VKR_DI float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu)
 VKR_DI void decode_node(const float4* np, NodeDec& n)
 {
     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-    const uint32_t eb = f2u(q0.w);
-    const float sx = u2f((eb & 0xffu) << 23), sy = u2f(((eb >> 8) & 0xffu) << 23), sz = u2f(((eb >> 16) & 0xffu) << 23);
-    n.nchild = eb >> 24;
+    const float sx = q2.z, sy = q2.w, sz = q0.w;
     const uint32_t wminx = f2u(q1.x), wminy = f2u(q1.y), wminz = f2u(q1.z), wmaxx = f2u(q1.w), wmaxy = f2u(q2.x),
                    wmaxz = f2u(q2.y);
 #pragma unroll
@@ -207,9 +211,9 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
             uint32_t k1 = box_key(nd.mnx[1], nd.mny[1], nd.mnz[1], nd.mxx[1], nd.mxy[1], nd.mxz[1], o, id, tmin, tb, 1u);
             uint32_t k2 = box_key(nd.mnx[2], nd.mny[2], nd.mnz[2], nd.mxx[2], nd.mxy[2], nd.mxz[2], o, id, tmin, tb, 2u);
             uint32_t k3 = box_key(nd.mnx[3], nd.mny[3], nd.mnz[3], nd.mxx[3], nd.mxy[3], nd.mxz[3], o, id, tmin, tb, 3u);
-            if (nd.nchild < 2u) k1 = 0xffffffffu;
-            if (nd.nchild < 3u) k2 = 0xffffffffu;
-            if (nd.nchild < 4u) k3 = 0xffffffffu;
+            if (nd.ref[1] == VKR_CHILD_NONE) k1 = 0xffffffffu;     // used slots are a prefix
+            if (nd.ref[2] == VKR_CHILD_NONE) k2 = 0xffffffffu;
+            if (nd.ref[3] == VKR_CHILD_NONE) k3 = 0xffffffffu;
             cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);  // ascending
             auto ref_of = [&](uint32_t key) -> uint32_t {
                 uint32_t s = key & 3u;
@@ -227,8 +231,7 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
         if (!alive) break;
         // ---- leaf
         {
-            uint32_t x = (uint32_t)(~cur);
-            uint32_t first = x & 0x0fffffffu, count = ((x >> 28) & 7u) + 1u;
+            uint32_t first = leaf_ref_first((uint32_t)cur), count = leaf_ref_count((uint32_t)cur);
             bool stop = false;
             for (uint32_t k = 0; k < count; ++k) {
                 uint32_t ti = first + k;

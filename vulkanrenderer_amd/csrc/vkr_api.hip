@@ -140,8 +140,8 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
         if ((e = c->d_ping[i].alloc(px)) != hipSuccess) return bail(VKR_ERR_OOM, "ping-pong image", e);
     }
     if ((e = c->d_nz.alloc(px)) != hipSuccess) return bail(VKR_ERR_OOM, "A-Trous operand", e);
-    if ((e = c->d_stats.alloc(8)) != hipSuccess) return bail(VKR_ERR_OOM, "counters", e);
-    if ((e = hipMemset(c->d_stats.p, 0, 64)) != hipSuccess) return bail(VKR_ERR_HIP, "hipMemset", e);
+    if ((e = c->d_stats.alloc(24)) != hipSuccess) return bail(VKR_ERR_OOM, "counters", e);
+    if ((e = hipMemset(c->d_stats.p, 0, 192)) != hipSuccess) return bail(VKR_ERR_HIP, "hipMemset", e);
     int rc = vkr_rtao_reset(c, nullptr);
     if (rc != VKR_OK) { g_create_error = c->err; vkr_destroy(c); return rc; }
     if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(VKR_ERR_HIP, "hipStreamSynchronize", e);
@@ -927,12 +927,18 @@ int vkr_trace_stats_get(vkr_ctx* c, vkr_trace_stats* out, int reset)
     if (!out) return fail(c, VKR_ERR_INVALID_ARG, "out is NULL");
     if (int rc = set_device(c)) return rc;
     HIP_OR_FAIL(c, hipDeviceSynchronize());
-    unsigned long long h[6];
-    HIP_OR_FAIL(c, hipMemcpy(h, c->d_stats.p, 48, hipMemcpyDeviceToHost));
+    unsigned long long h[24];
+    HIP_OR_FAIL(c, hipMemcpy(h, c->d_stats.p, 192, hipMemcpyDeviceToHost));
+    if (getenv("VKR_PHASE_DUMP")) {   // development: per-phase shader cycles of the K1 STATS build, summed over waves (k_trace_q)
+        static const char* names[8] = {"setup_raygen", "inject", "node_steps", "leaf_steps", "alpha_steps", "retry_list", "resolve", "tile_pull"};
+        fprintf(stderr, "{\"k1_phase_cycles\": {");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, "\"%s\": %llu, ", names[k], h[8 + k]);
+        fprintf(stderr, "\"n_node_steps\": %llu, \"n_leaf_steps\": %llu, \"n_alpha_steps\": %llu, \"node_items\": %llu, \"waves\": %llu, \"spilled_items\": %llu}}\n", h[16], h[17], h[18], h[19], h[20], h[5]);
+    }
     out->overflow_tiles = h[5];
     out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
     out->wave_node_iters = h[3]; out->wave_tri_iters = h[4];
-    if (reset) HIP_OR_FAIL(c, hipMemset(c->d_stats.p, 0, 64));
+    if (reset) HIP_OR_FAIL(c, hipMemset(c->d_stats.p, 0, 192));
     return VKR_OK;
 }
 
