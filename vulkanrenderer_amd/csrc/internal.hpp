@@ -152,7 +152,9 @@ struct vkr_ctx {
     // ---- RTAO images (FrameManager::createRtaoComputeTextures)
     vkr::DevBuf<uint16_t> d_hist_img[2], d_ping[2];
     vkr::DevBuf<float4> d_raybuf;            // K1 ray slices: per wave (2 float4/ray + retry list), grow-only
-    vkr::DevBuf<uint32_t> d_tile_counter;    // K1 persistent waves pull tiles from it
+    vkr::DevBuf<uint32_t> d_tile_counter;    // K1 persistent waves pull items from it (8 counters, 64 B apart)
+    vkr::DevBuf<float4> d_shq_raybuf;        // k_shadow_q: its own ray slices and chunk counter, so a shadow launch on a
+    vkr::DevBuf<uint32_t> d_shq_counter;     // second stream can overlap K1 (point lights always; sun under VKR_SUN_MODE=ray)
     vkr::DevBuf<uint8_t> d_sun_frame;        // K4 packet form: the frame's sample directions (SunFrame)
     int sun_reserve_waves = 4;               // K4 packet form: wave slots per CU left free (VKR_SUN_RESERVE_WAVES)
     vkr::DevBuf<uint32_t> d_sun_counter;     // K4 packet form: chunk counter of its persistent waves (separate from K1's)

@@ -561,8 +561,8 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #ifndef K1_NQ
 #define K1_NQ 512          // node queue entries in LDS
 #endif
-#ifndef K1_CHUNK
-#define K1_CHUNK 1         // work items a wave pulls from the counter at a time
+#ifndef K1_SLABS
+#define K1_SLABS 8         // work counters: 1 = one row-major list, 8 = one vertical slab of tile columns per XCD
 #endif
 #ifndef K1_LQ
 #define K1_LQ 256          // leaf queue entries in LDS (>= 64; a node step's leaf pushes beyond it go to the global stack)
@@ -643,23 +643,34 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     uint32_t ph_n[4] = {0, 0, 0, 0};             // node steps / leaf steps / alpha steps / node items
 #define VKR_STAMP(K) { if (STATS) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph[K] += now_ - ph_prev; ph_prev = now_; } }
 
-    uint32_t chunk_next = 0, chunk_end = 0;
+    // Work distribution.  K1_SLABS == 1: one counter, items in row-major order.  K1_SLABS == 8: the tile columns are cut
+    // into 8 vertical slabs with a counter each; a wave starts on the slab of its own XCD (HW_REG_XCC_ID) and moves on to
+    // the next slab when that one is drained, so the waves that share an L2 work on neighbouring pixels (speed only: any
+    // wave may take any item).
+    uint32_t slab = 0, slabs_done = 0;
+    if (K1_SLABS > 1) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        slab = (xcc & 0xfu) % (uint32_t)K1_SLABS;
+    }
+    const uint32_t item_rows = n_items / tiles_x;             // rows of items in the launch
     for (;;) {
-        // items are pulled K1_CHUNK at a time: consecutive items are neighbouring pixel blocks, and a wave that walks them
-        // one after the other finds most of their nodes and triangles still in its CU's L1
-        if (chunk_next == chunk_end) {
-            uint32_t first = 0;
-            if (lane == 0) first = atomicAdd(tile_counter, (uint32_t)K1_CHUNK);
-            chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-            chunk_end = chunk_next + (uint32_t)K1_CHUNK;
+        uint32_t item = 0;
+        const uint32_t c0 = slab * tiles_x / (uint32_t)K1_SLABS, c1 = (slab + 1u) * tiles_x / (uint32_t)K1_SLABS;
+        const uint32_t slab_items = (c1 - c0) * item_rows;
+        if (lane == 0) item = atomicAdd(tile_counter + slab * 16u, 1u);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= slab_items) {                               // this slab is drained (every wave gets here: counters only grow)
+            if (++slabs_done >= (uint32_t)K1_SLABS) break;
+            slab = (slab + 1u) % (uint32_t)K1_SLABS;
+            continue;
         }
-        const uint32_t item = chunk_next++;
-        if (item >= n_items) break;          // every wave reaches this: the counter only grows
         VKR_STAMP(7)
-        const uint32_t r_ = item / tiles_x;                                   // row of items: 8-row stripe * sub-block
+        const uint32_t r_ = item / (c1 - c0);                                 // row of items: 8-row stripe * sub-block
+        const uint32_t tile_x = c0 + item % (c1 - c0);
         const uint32_t sub = r_ % items_per_block, trow = r_ / items_per_block;
         const uint32_t idx = sub * (uint32_t)P + (uint32_t)plane;             // pixel of the 8x8 block, row-major
-        const int px = (int)(item % tiles_x) * 8 + (int)(idx & 7u);
+        const int px = (int)tile_x * 8 + (int)(idx & 7u);
         const int py = y0 + (int)trow * 8 * fp.stripeMul + (int)(idx >> 3);
 
         // ------------------------------------------------------------------ phase 1: per pixel
@@ -1027,8 +1038,8 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
         if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
     }
-    if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(1)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
+    if (c->d_tile_counter.n < 16u * 8u && (e = c->d_tile_counter.alloc(16u * 8u)) != hipSuccess) return e;   // 8 counters, 64 B apart
+    if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 16u * 8u * 4u, st)) != hipSuccess) return e;
     k_trace_q<STATS, RB><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, n_items,
                                                         c->d_raybuf.p, c->d_tile_counter.p, STATS ? c->d_stats.p : nullptr);
     return hipGetLastError();

@@ -874,14 +874,16 @@ static hipError_t shadow_q_launch(vkr_ctx* c, int mode, const ShadowArgs& sa, hi
     uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
     if (blocks > n_chunks) blocks = n_chunks;
     const size_t need = mode == 0 ? 1 : (size_t)blocks * SQ_POINT_PIX * 3;
-    if (c->d_raybuf.n < need) {
+    // own scratch (chunk counter + ray slices): a shadow launch on a second stream may overlap K1, which keeps
+    // d_tile_counter / d_raybuf for itself
+    if (c->d_shq_raybuf.n < need) {
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-        if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
+        if ((e = c->d_shq_raybuf.alloc(need)) != hipSuccess) return e;
     }
-    if (!c->d_tile_counter.p && (e = c->d_tile_counter.alloc(1)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 4, st)) != hipSuccess) return e;
-    if (mode == 0) k_shadow_q<0><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_raybuf.p, c->d_tile_counter.p);
-    else k_shadow_q<1><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_raybuf.p, c->d_tile_counter.p);
+    if (!c->d_shq_counter.p && (e = c->d_shq_counter.alloc(1)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c->d_shq_counter.p, 0, 4, st)) != hipSuccess) return e;
+    if (mode == 0) k_shadow_q<0><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_shq_raybuf.p, c->d_shq_counter.p);
+    else k_shadow_q<1><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_shq_raybuf.p, c->d_shq_counter.p);
     return hipGetLastError();
 }
 
