@@ -65,9 +65,29 @@ def event_time_ms(fn, stream_sync):
     return e0.elapsed_time(e1)
 
 
-def cpu_baseline(scene, wl, ubos, gb0_depth, gb0_normal, target_seconds):
-    """Time the CPU oracle (kind "port") on a bounded sample of the same workload: K1 (trace+temporal) on a band of
-    rows of frame 0, all host threads the box grants us."""
+def _oracle_chain_band(O, osc, ubo, depth, normal, hist_prev, iters, ya, yb):
+    """RtaoComputePass on the CPU for output rows [ya, yb): K1 on the rows + the A-Trous halo, then `iters` A-Trous
+    iterations whose row range shrinks by 2*step each (the last one = rtao_full, upsample folded).  Returns
+    (rtao_full rows, history rows, seconds K1, seconds A-Trous)."""
+    H, W = depth.shape
+    halo = 2 * ((1 << iters) - 1)
+    t0, t1 = max(0, ya - halo), min(H, yb + halo)
+    a = time.perf_counter()
+    cur = osc.trace(ubo, depth, hist_prev, t0, t1)
+    b = time.perf_counter()
+    src = np.asarray(cur).view(np.uint16).reshape(H, W)
+    for i in range(iters):
+        rem = 2 * ((1 << iters) - (1 << (i + 1)))          # halo rows the later iterations still need
+        src = O.atrous(ubo, 1 << i, src, depth, normal, max(0, ya - rem), min(H, yb + rem))
+    c = time.perf_counter()
+    return src[ya:yb], np.asarray(cur).view(np.uint16).reshape(H, W)[ya:yb], b - a, c - b
+
+
+def cpu_baseline(scene, wl, ubo, gb0_depth, gb0_normal, target_seconds, c0=None):
+    """Time the CPU oracle (kind "port") on bounded samples of the same workload, whole chain (K1 trace+temporal + N x A-Trous,
+    upsample folded into the last store): all host threads the box grants us AND one thread.
+    Sample 1: a row band of the first timed C3 frame (sized for ~target_seconds).  Sample 2 (c0 = (scene, ubo, depth, normal)):
+    BASELINE configs[0] in full -- sponza-class 640x360, 4 rays/px, 2 A-Trous iterations."""
     from oracle import oracle as O
     W, H, rays, iters, sun, _ = wl
     threads = min(16, len(os.sched_getaffinity(0)))
@@ -77,25 +97,47 @@ def cpu_baseline(scene, wl, ubos, gb0_depth, gb0_normal, target_seconds):
     build_s = time.perf_counter() - t0
     hist = np.full((H, W), np.float16(1.0).view(np.uint16), dtype=np.uint16)
     ymid = H // 2
-    # calibrate on 8 rows, then size the band for ~target_seconds
-    osc.stats(reset=True)
+    # calibrate on 8 rows, then size the band: ~60 % of the budget all-core, ~40 % single-thread
     t0 = time.perf_counter()
-    osc.trace(ubos[0], gb0_depth, hist, ymid, ymid + 8)
-    dt = time.perf_counter() - t0
-    rows = int(max(8, min(H - ymid, 8 * target_seconds / max(dt, 1e-6))))
+    osc.trace(ubo, gb0_depth, hist, ymid, ymid + 8)
+    dt8 = time.perf_counter() - t0
+    halo = 2 * ((1 << iters) - 1)
+    rows = int(max(8, min(H - ymid - halo, 8 * 0.6 * target_seconds / max(dt8, 1e-6) - 2 * halo)))
     osc.stats(reset=True)
-    t0 = time.perf_counter()
-    cur = osc.trace(ubos[0], gb0_depth, hist, ymid, ymid + rows)
-    dt = time.perf_counter() - t0
+    full_rows, hist_rows, t_k1, t_at = _oracle_chain_band(O, osc, ubo, gb0_depth, gb0_normal, hist, iters, ymid, ymid + rows)
     st = osc.stats(reset=True)
-    # A-Trous on the same band (one iteration) for the ms/frame side of the metric
-    t1 = time.perf_counter()
-    O.atrous(ubos[0], 1, cur, gb0_depth, gb0_normal, ymid, ymid + rows)
-    dta = time.perf_counter() - t1
-    return (ymid, ymid + rows, cur), {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"oracle K1 trace+temporal on rows [{ymid},{ymid + rows}) of frame 0 at {W}x{H}, {rays} rays/px "
-                      f"({st['rays']} rays in {dt:.2f} s; CPU BVH build {build_s:.1f} s not counted); "
-                      f"one A-Trous iteration on the same rows {dta * 1e3:.0f} ms"}
+    out = {"value": st["rays"] / (t_k1 + t_at) / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": f"oracle whole chain (K1 trace+temporal on rows [{max(0, ymid - halo)},{min(H, ymid + rows + halo)}) + {iters} A-Trous iterations "
+                     f"-> rtao_full rows [{ymid},{ymid + rows})) of the first timed frame at {W}x{H}, {rays} rays/px: {st['rays']} rays, "
+                     f"K1 {t_k1:.2f} s + A-Trous {t_at:.2f} s on {threads} threads; CPU BVH build {build_s:.1f} s not counted",
+           "band_ms": {"rows": rows, "k1": t_k1 * 1e3, "atrous": t_at * 1e3},
+           "frame_ms_extrapolated_by_rows": (t_k1 + t_at) * 1e3 * H / rows}
+    # one thread: a band 1/threads as tall for about the same wall time
+    O.set_threads(1)
+    rows1 = int(max(4, min(rows, rows * 0.7 / threads + 1)))
+    osc.stats(reset=True)
+    _, _, t1_k1, t1_at = _oracle_chain_band(O, osc, ubo, gb0_depth, gb0_normal, hist, iters, ymid, ymid + rows1)
+    st1 = osc.stats(reset=True)
+    out["single_thread"] = {"value": st1["rays"] / (t1_k1 + t1_at) / 1e6, "unit": "Mrays/s", "cores": 1,
+                            "band_ms": {"rows": rows1, "k1": t1_k1 * 1e3, "atrous": t1_at * 1e3},
+                            "frame_ms_extrapolated_by_rows": (t1_k1 + t1_at) * 1e3 * H / rows1}
+    if c0 is not None:
+        sc0, ubo0, d0, n0 = c0
+        H0, W0 = d0.shape
+        o0 = O.OracleScene(sc0)
+        res = {}
+        for nthr in (threads, 1):
+            O.set_threads(nthr)
+            p0 = O.OracleRtaoPass(o0, W0, H0, 2)
+            o0.stats(reset=True)
+            t0 = time.perf_counter()
+            p0.execute(ubo0, d0, n0)
+            dt = time.perf_counter() - t0
+            r0 = o0.stats(reset=True)["rays"]
+            res["all_cores" if nthr != 1 else "one_core"] = {"cores": nthr, "ms_per_frame": dt * 1e3, "mrays_per_s": r0 / dt / 1e6}
+        out["c0_full_frame"] = {"workload": f"c0: {sc0.name} {W0}x{H0}, 4 AO rays/px + temporal + 2 A-Trous iters (BASELINE configs[0]), one frame from cleared history", **res}
+    O.set_threads(threads)
+    return (ymid, ymid + rows, full_rows, hist_rows), out
 
 
 def log(msg):
@@ -259,13 +301,17 @@ def main():
     rehearse = os.environ.get("VKR_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    # --gpus N is a statement about the launcher: N ranks (torch.distributed.run sets WORLD_SIZE).  Without them the N>1
+    # schedule would trace 1/N of the frame and report it as the whole job, so refuse.
+    if world != n:
+        sys.exit(f"bench.py: --gpus {n} but WORLD_SIZE is {world}: launch with python -m torch.distributed.run --nproc-per-node {n} "
+                 f"--master-addr 127.0.0.1 bench.py --gpus {n} ...")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        assert world == n, f"--gpus {n} but WORLD_SIZE {world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -468,29 +514,59 @@ def main():
             t_up.append(event_time_ms(lambda: rpass.dispatchUpsample(ubos[i]), None))
             rpass.endFrame()
         trace_ms = float(np.mean(t_trace))
-        # algorithmic bytes of one K1 launch: 8 B/px of image traffic + BVH traffic
-        # = visited nodes * 64 B + tested triangles * 48 B (this build's node / triangle record sizes)
+        atrous_ms = float(np.mean(t_atrous))
         px = W * H
-        bytes_per_launch = 8.0 * px + (st.nodes_visited * 64.0 + st.tris_tested * 48.0) / K
-        achieved = bytes_per_launch / (trace_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_trace_q (K1 trace+temporal)", "achieved": achieved,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                           "launch_ms": trace_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "nodes_per_ray": st.nodes_visited / max(1, ao_rays), "tris_per_ray": st.tris_tested / max(1, ao_rays),
-                           "lane_util_node_loop": st.nodes_visited / max(1, 64 * st.wave_node_iters),
-                           "lane_util_tri_loop": st.tris_tested / max(1, 64 * st.wave_tri_iters),
-                           # every byte that has to come from HBM at least once: the images + (at most) the whole BVH
-                           "compulsory_bytes_per_launch": 8.0 * px + info.node_count * 64.0 + info.triangle_count * 48.0,
-                           "frac_compulsory": (8.0 * px + info.node_count * 64.0 + info.triangle_count * 48.0)
-                                              / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "achieved = SURVEY 8(d) algorithmic bytes (8 B/px + 64 B per node visit + 48 B per "
-                                   "triangle test) / launch time; node and triangle re-reads are served by L1/L2, so the "
-                                   "figure can exceed the HBM peak -- the kernel is VALU-issue bound (profiles/), and "
-                                   "`traffic` is the HBM-side byte count measured with rocprofv3 PMC counters"}
+        # ---- K1 roofline.  The kernel is bound by vector-instruction issue (and, next to it, by the L1 return path): see
+        # DESIGN.md 4.  achieved = wave-level VALU instructions of one launch / launch time (HIP events, this run);
+        # peak = 1024 SIMDs x 2.4 GHz / (calibrated issue cycles per instruction for K1's instruction mix).  The
+        # instruction count and the mix are properties of the code + workload, measured once with rocprofv3 --pmc /
+        # the ISA census and read from profiles/ (named in `source`); the issue costs come from tools/calib/issue_rates*.
+        cal = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r2_k1_valu_model.json")) as f:
+                cal = json.load(f)
+        except Exception:
+            cal = {}
+        # SURVEY 8(d)'s byte figure (8 B/px + 64 B per node visit + 48 B per triangle test): bytes served by L1/L2, NOT HBM
+        cache_side = 8.0 * px + (st.nodes_visited * 64.0 + st.tris_tested * 48.0) / K
+        compulsory = 8.0 * px + info.node_count * 64.0 + info.triangle_count * 48.0
+        roof = {"kernel": "k_trace_q (K1 trace+temporal)", "launch_ms": trace_ms,
+                "nodes_per_ray": st.nodes_visited / max(1, ao_rays), "tris_per_ray": st.tris_tested / max(1, ao_rays),
+                "lane_util_node_loop": st.nodes_visited / max(1, 64 * st.wave_node_iters),
+                "lane_util_tri_loop": st.tris_tested / max(1, 64 * st.wave_tri_iters),
+                "cache_side_bytes_per_launch": cache_side, "cache_side_gbs": cache_side / (trace_ms * 1e-3) / 1e9,
+                "compulsory_bytes_per_launch": compulsory,
+                "hbm_frac_compulsory": compulsory / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if cal.get("workload") == wl_name:
+            insts = float(cal["valu_insts_per_launch"])
+            cyc = float(cal["mean_issue_cycles_per_valu_inst"])
+            peak = 1024 * 2.4e9 / cyc / 1e9                      # G wave-instructions/s the chip can issue for this mix
+            ach = insts / (trace_ms * 1e-3) / 1e9
+            roof.update({"bound": "valu", "achieved": ach, "peak": peak, "unit": "G wave-inst/s", "frac": ach / peak,
+                         "traffic": cal.get("hbm_bytes_per_launch"), "traffic_frac_of_hbm_peak": cal.get("hbm_bytes_per_launch", 0.0) / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "td_busy_frac": cal.get("td_busy_frac"), "l1_hit_rate": cal.get("l1_hit_rate"), "l2_hit_rate": cal.get("l2_hit_rate"),
+                         "source": cal.get("source"),
+                         "note": "achieved/peak/frac: VALU issue (the binding resource, DESIGN.md 4).  Instruction count, mix, traffic, TD busy and "
+                                 "hit rates were measured with rocprofv3 --pmc on this workload and are read from the file named in `source`; "
+                                 "launch_ms is this run's HIP-event time.  cache_side_bytes is SURVEY 8(d)'s figure: bytes served by L1/L2, not HBM."})
+        else:
+            roof.update({"bound": "hbm", "achieved": compulsory / (trace_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": compulsory / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "no PMC model committed for this workload: compulsory bytes (images + the whole BVH once) against the HBM peak"})
+        out["roofline"] = roof
+        # ---- K2 roofline: HBM, 14 B/px per iteration
         atrous_bytes = 14.0 * px * iters
-        out["kernels"] = {"trace_ms": trace_ms, "atrous_total_ms": float(np.mean(t_atrous)), "upsample_ms": float(np.mean(t_up)),
+        out["roofline_k2"] = {"bound": "hbm", "kernel": f"k_prep + {iters} x k_atrous_tile (K2, upsample folded into the last store)",
+                              "achieved": atrous_bytes / (atrous_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": atrous_bytes / (atrous_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "traffic": cal.get("k2_hbm_bytes_per_iteration") if cal.get("workload") == wl_name else None,
+                              "launch_ms": atrous_ms, "algorithmic_bytes": atrous_bytes,
+                              "source": cal.get("source") if cal.get("workload") == wl_name else None,
+                              "note": "VALU-bound by contract: two software exp (bit-exact against the oracle) + pow32 per tap, ~57 "
+                                      "instructions x 25 taps per pixel; the v_exp_f32 build (VKR_ATROUS=tol, outside the contract) is timed in DESIGN.md"}
+        out["kernels"] = {"trace_ms": trace_ms, "atrous_total_ms": atrous_ms, "upsample_ms": float(np.mean(t_up)),
                           "ao_mrays_per_s_kernel": ao_rays / K / (trace_ms * 1e-3) / 1e6,
-                          "atrous_gbs_algorithmic": atrous_bytes / (float(np.mean(t_atrous)) * 1e-3) / 1e9,
+                          "atrous_gbs_algorithmic": atrous_bytes / (atrous_ms * 1e-3) / 1e9,
                           "first_build_incl_upload_s": first_build_s}
         # RayTracingContext::updateTopLevelAS on unchanged transforms: re-transform + refit of the resident BVH
         from vulkanrenderer_amd.renderer import instances_to_array
@@ -505,37 +581,43 @@ def main():
             # point light's shadow rays over the whole frame (pbr.frag:169-196, light 0 of FrameManager.cpp:477-483)
             tp = [event_time_ms(lambda: (setattr(shadows, "gb", gbs[i]), shadows.point(ubos[i], 0)), None) for i in range(Wu, Wu + min(K, 5))]
             out["kernels"]["point_shadow_ms_full_frame_per_light"] = float(np.mean(tp))
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
-            try:
-                with open(prof) as f:
-                    pj = json.load(f)
-                if pj.get("workload") == wl_name:
-                    out["roofline"]["traffic"] = pj.get("k_trace_hbm_bytes_per_launch")
-                    for k in ("valu_busy_frac", "l2_hit_rate", "l1_hit_rate"):
-                        if k in pj:
-                            out["roofline"][k] = pj[k]
-            except Exception:
-                pass
 
     if rank == 0 and n == 1 and args.cpu_seconds > 0:
         depth0 = gbs[Wu].linear_depth.cpu().numpy().view(np.uint16)
         normal0 = gbs[Wu].normal.cpu().numpy().view(np.uint16)
-        (ya, yb, want), out["cpu_baseline"] = cpu_baseline(scene, wl, [ubos[Wu]], depth0, normal0, args.cpu_seconds)
-        # the oracle is the checker here too: the GPU's trace+temporal output for the same frame, from the same cleared
-        # history, against the rows the CPU leg just computed (the parity tests proper are tests/ -m gpu)
+        # BASELINE configs[0] in full for the CPU leg: sponza-class 640x360, 4 rays, 2 iterations (G-buffer from the GPU producer)
+        c0 = None
+        if wl_name == "c3" and not os.environ.get("VKR_BENCH_NO_C0"):
+            W0, H0 = WORKLOADS["c0"][0], WORKLOADS["c0"][1]
+            sc0 = make_scene("sponza")
+            ctx0 = Context(W0, H0, local_rank)
+            rt0 = RayTracingContext(ctx0)
+            rt0.init(sc0)
+            fs0 = FrameState(W0, H0, ray_count=4)
+            e0, t0_ = camera_path(sc0, 1, step=0.05)[0]
+            ubo0 = fs0.update(e0, t0_)
+            gb0 = GBuffer(ctx0)
+            generate_gbuffer(ctx0, ubo0, gb0)
+            ctx0.sync()
+            c0 = (sc0, ubo0, gb0.linear_depth.cpu().numpy().view(np.uint16), gb0.normal.cpu().numpy().view(np.uint16))
+        (ya, yb, want_full, want_hist), out["cpu_baseline"] = cpu_baseline(scene, wl, ubos[Wu], depth0, normal0, args.cpu_seconds, c0)
+        # the oracle is the checker here too: the GPU's whole pass (K1 + A-Trous x N, upsample folded) for the same frame, from
+        # the same cleared history, against the rows the CPU leg just computed (the parity tests proper are tests/ -m gpu)
         rpass.band = None
         rpass.reset()
         rpass.gbuffer = gbs[Wu]
-        rpass.dispatchTrace(ubos[Wu])
+        rpass.execute(PassExecuteContext(ubo=ubos[Wu]))
         ctx.sync()
-        got = rpass.image(0).cpu().numpy().view(np.uint16).reshape(H, W)[ya:yb]
-        ref = np.asarray(want).view(np.uint16).reshape(H, W)[ya:yb]
-        diff = np.abs(got.view(np.float16).astype(np.float32) - ref.view(np.float16).astype(np.float32))
-        out["parity"] = {"checked": f"K1 trace+temporal, rows [{ya},{yb}) of the first timed frame, GPU vs CPU oracle (R16F bits)",
-                         "pixels": int(got.size), "mismatching_pixels": int((got != ref).sum()),
+        got_full = rpass.rtao_full.cpu().numpy().view(np.uint16).reshape(H, W)[ya:yb]
+        got_hist = rpass.image(0).cpu().numpy().view(np.uint16).reshape(H, W)[ya:yb]
+        ref_full = np.asarray(want_full).view(np.uint16)
+        ref_hist = np.asarray(want_hist).view(np.uint16)
+        diff = np.abs(got_full.view(np.float16).astype(np.float32) - ref_full.view(np.float16).astype(np.float32))
+        out["parity"] = {"checked": f"rtao_full (K1 trace+temporal + {iters} A-Trous iterations) and the K1 history, rows [{ya},{yb}) of the first timed "
+                                    "frame, GPU vs CPU oracle (R16F bits)",
+                         "pixels": int(got_full.size), "mismatching_pixels": int((got_full != ref_full).sum()),
+                         "mismatching_history_pixels": int((got_hist != ref_hist).sum()),
                          "pixels_over_1_255": int((diff > 1.0 / 255.0).sum()), "max_abs_diff": float(diff.max())}
-        rpass.endFrame()
 
     if rank == 0:
         print(json.dumps(out))

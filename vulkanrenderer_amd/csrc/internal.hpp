@@ -159,6 +159,7 @@ struct vkr_ctx {
     int sun_reserve_waves = 4;               // K4 packet form: wave slots per CU left free (VKR_SUN_RESERVE_WAVES)
     vkr::DevBuf<uint32_t> d_sun_counter;     // K4 packet form: chunk counter of its persistent waves (separate from K1's)
     bool sun_packets = true;                 // K4 form: one packet per pixel (k_shadow_sun_pkt) or one item per ray (k_shadow_q)
+    int atrous_mode = 1;                     // K2 form: 1 LDS-tiled (default), 0 per-pixel gathers (VKR_ATROUS=gather), 2 tiled + v_exp_f32 (VKR_ATROUS=tol, outside the bit-exact contract)
     bool trace_streaming = true;             // K1 form: wave-wide queues (k_trace_q) or one ray per lane (k_trace)
     int num_cus = 0;
     vkr::DevBuf<float4> d_nz;                // per-frame decoded normal.xyz + clamped depth (A-Trous operand)

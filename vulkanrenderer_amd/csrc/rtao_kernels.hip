@@ -628,7 +628,6 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     uint32_t* retry_list = (uint32_t*)(g_dir + lay.dir_f4);
     uint32_t* g_nq = (uint32_t*)(g_dir + lay.dir_f4 + lay.retry_f4);
     uint32_t* g_lq = g_nq + K1_GNQ;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const char* node_base = (const char*)sc.nodes;
     const char* tri_base = (const char*)sc.tris;
     TraceCounters cnt{0, 0, 0, 0};
@@ -1161,6 +1160,92 @@ __global__ __launch_bounds__(256) void k_atrous(const uint16_t* src, const float
     if (dst2) dst2[o] = r;
 }
 
+// K2, tiled form (the default).  The 25 taps of a pixel sit at multiples of `step`, so the pixels with equal
+// (x mod step, y mod step) form a sub-image on which the filter is a dense 5x5 stencil.  One workgroup filters a 32x8
+// tile of one sub-image: its 36x12 operand texels {AO as float, normal.xyz, depth} are fetched ONCE into LDS (each
+// texel is the one the tap's clamp-to-edge address names, so edges need no special case), and the 25 taps then read LDS
+// at immediate offsets -- no per-tap address arithmetic, no per-tap fp16 conversion, one global fetch per texel
+// instead of 25 (steps 1..16 alike).  Arithmetic per tap is the shader's (:90-110), in the same order as k_atrous;
+// exp's final scaling by 2^k is v_ldexp_f32, which rounds exactly like the multiplication by the float 2^k.
+// TOL (build/ env switch, NOT the default): range and depth weights through v_exp_f32 -- outside the bit-exact contract,
+// measured against the oracle in DESIGN.md.
+constexpr int AT_TX = 32, AT_TY = 8, AT_LW = AT_TX + 4, AT_LH = AT_TY + 4;
+
+VKR_DI float det_exp_ld(float x)   // det_exp with v_ldexp_f32 for the last step (same bits: both forms round once)
+{
+    float k = __builtin_rintf(x * 1.44269504088896341f);
+    float r = fma_(k, -0.693359375f, x);
+    r = fma_(k, 2.12194440e-4f, r);
+    float p = fma_(r, 1.9875691500E-4f, 1.3981999507E-3f);
+    p = fma_(r, p, 8.3334519073E-3f);
+    p = fma_(r, p, 4.1665795894E-2f);
+    p = fma_(r, p, 1.6666665459E-1f);
+    p = fma_(r, p, 5.0000001201E-1f);
+    p = fma_(r * r, p, r) + 1.0f;
+    float res = __builtin_ldexpf(p, (int)k);
+    return (x < -87.0f) ? 0.0f : res;
+}
+
+template <bool TOL>
+__global__ __launch_bounds__(256) void k_atrous_tile(const uint16_t* src, const float4* nz, uint16_t* dst, uint16_t* dst2,
+                                                     int W, int H, int y0, int y1, int step, float sigmaAbs)
+{
+    __shared__ float4 s_nz[AT_LH][AT_LW];
+    __shared__ float s_ao[AT_LH][AT_LW];
+    const int sub = (int)blockIdx.z, sa = sub % step, sb = sub / step;            // sub-image (x mod step, row offset in the band)
+    const int i0 = (int)blockIdx.x * AT_TX, j0 = (int)blockIdx.y * AT_TY;          // tile origin in sub-image coordinates
+    for (int t = (int)threadIdx.x; t < AT_LW * AT_LH; t += 256) {
+        const int ly = t / AT_LW, lx = t - ly * AT_LW;
+        const int gx = iclamp(sa + step * (i0 + lx - 2), 0, W - 1);                // = clamp(px + x*step) of :81 for every tap that reads it
+        const int gy = iclamp(y0 + sb + step * (j0 + ly - 2), 0, H - 1);
+        const size_t to = (size_t)gy * W + gx;
+        s_ao[ly][lx] = half_to_float(src[to]);                                      // :82-89
+        s_nz[ly][lx] = nz[to];                                                      // :92-94
+    }
+    __syncthreads();
+    const int tx = (int)threadIdx.x & (AT_TX - 1), ty = (int)threadIdx.x >> 5;
+    const int px = sa + step * (i0 + tx), py = y0 + sb + step * (j0 + ty);
+    if (px >= W || py >= y1) return;
+    const float center = s_ao[ty + 2][tx + 2];                                      // :62-69
+    const float4 cn = s_nz[ty + 2][tx + 2];                                         // :70-72
+    const float centerZ = cn.w;
+    const V3 centerN = V3{cn.x, cn.y, cn.z};
+    float sum = 0.0f, weightSum = 0.0f;
+    const float sigmaRel = 0.0025f;                                                 // :102
+    const float stepScale = 1.0f + 0.25f * (float)step;                             // :104
+    const float invZden = 1.0f / gmax(centerZ, 1e-3f);                              // reciprocal form of the three quotients: DESIGN.md 2
+    const float invSigmaAbs = 1.0f / sigmaAbs, invSigmaRel = 1.0f / sigmaRel;
+#pragma unroll
+    for (int y = -2; y <= 2; ++y) {                                                 // :78-112
+#pragma unroll
+        for (int x = -2; x <= 2; ++x) {
+            const float s = s_ao[ty + 2 + y][tx + 2 + x];
+            const float4 tn = s_nz[ty + 2 + y][tx + 2 + x];
+            const float spatial = det_exp(-0.5f * (float)(x * x + y * y));          // :90 (a compile-time constant per tap)
+            const float rarg = -__builtin_fabsf(s - center) * 8.0f;
+            const float range = TOL ? __builtin_amdgcn_exp2f(rarg * 1.44269504088896341f) : det_exp_ld(rarg);   // :91
+            const float dz = __builtin_fabsf(tn.w - centerZ);                       // :98
+            const float dzRel = dz * invZden;                                       // :99
+            float depthNorm = gmax(dz * invSigmaAbs, dzRel * invSigmaRel);          // :103
+            depthNorm *= stepScale;                                                 // :104
+            const float darg = -depthNorm * depthNorm;
+            const float depthWeight = TOL ? __builtin_amdgcn_exp2f(darg * 1.44269504088896341f) : det_exp_ld(darg);   // :105
+            // dot of two unit (or (0,1,0)) vectors is never NaN: the median form equals clamp(x, 0, 1) up to the sign of a zero,
+            // which the squarings below remove
+            const float nd = __builtin_amdgcn_fmed3f(dot3(centerN, V3{tn.x, tn.y, tn.z}), 0.0f, 1.0f);
+            const float normalWeight = pow32(nd);                                   // :107
+            const float w = ((spatial * range) * depthWeight) * normalWeight;       // :108
+            sum += s * w;                                                           // :109
+            weightSum += w;                                                         // :110
+        }
+    }
+    const size_t o = (size_t)py * W + px;
+    const float filtered = (weightSum > 0.0f) ? (sum / weightSum) : center;         // :114
+    const uint16_t r = float_to_half(filtered);
+    dst[o] = r;                                                                     // :115-119
+    if (dst2) dst2[o] = r;
+}
+
 hipError_t rtao_atrous_launch(vkr_ctx* c, float radius_raw, int step, const uint16_t* src, uint16_t* dst,
                               uint16_t* dst2, int y0, int y1, hipStream_t st)
 {
@@ -1169,8 +1254,18 @@ hipError_t rtao_atrous_launch(vkr_ctx* c, float radius_raw, int step, const uint
     if (!(radius_raw == radius_raw)) radius = radius_raw;                       // GLSL max(NaN, y) = NaN
     float sigmaAbs = (0.01f < radius * 0.05f) ? radius * 0.05f : 0.01f;         // :101
     if (step < 1) step = 1;                                                     // :76
-    dim3 grid((c->W + 31u) / 32u, ((uint32_t)(y1 - y0) + 7u) / 8u);
-    k_atrous<<<grid, 256, 0, st>>>(src, c->d_nz.p, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
+    if (c->atrous_mode == 0 || step > 64) {                                     // VKR_ATROUS=gather: one thread per pixel, 25 global gathers
+        dim3 grid((c->W + 31u) / 32u, ((uint32_t)(y1 - y0) + 7u) / 8u);
+        k_atrous<<<grid, 256, 0, st>>>(src, c->d_nz.p, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
+        return hipGetLastError();
+    }
+    const uint32_t sw = ((uint32_t)c->W + (uint32_t)step - 1u) / (uint32_t)step;            // sub-image extent
+    const uint32_t sh = ((uint32_t)(y1 - y0) + (uint32_t)step - 1u) / (uint32_t)step;
+    dim3 grid((sw + AT_TX - 1u) / AT_TX, (sh + AT_TY - 1u) / AT_TY, (uint32_t)(step * step));
+    if (c->atrous_mode == 2)
+        k_atrous_tile<true><<<grid, 256, 0, st>>>(src, c->d_nz.p, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
+    else
+        k_atrous_tile<false><<<grid, 256, 0, st>>>(src, c->d_nz.p, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
     return hipGetLastError();
 }
 

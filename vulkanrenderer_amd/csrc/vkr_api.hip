@@ -124,6 +124,7 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     if (const char* e = getenv("VKR_REFIT")) c->refit_wide = (e[0] != 'b');             // "binary" = k_fit + k_wide_refit
     if (const char* e = getenv("VKR_SUN_RESERVE_WAVES")) { int v = atoi(e); c->sun_reserve_waves = v < 0 ? 0 : (v > 16 ? 16 : v); }
     if (const char* e = getenv("VKR_VALIDATE_TREE")) c->validate_tree = (e[0] == '1');
+    if (const char* e = getenv("VKR_ATROUS")) c->atrous_mode = !strcmp(e, "gather") ? 0 : (!strcmp(e, "tol") ? 2 : 1);
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
     if (const char* e = getenv("VKR_SUN_MODE")) c->sun_packets = (e[0] != 'r');         // "ray" = one queue item per ray
     (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, c->device);
