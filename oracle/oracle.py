@@ -449,6 +449,12 @@ class OracleRtaoPass:
         return (full, mask) if want_mask else full
 
 
+def set_variant(v: int):
+    """Contract-departure switches of the oracle (tests only; 0 = the contract): 1 IEEE divisions in A-Trous, 2 A-Trous
+    fetches through the samplers at the computed uv, 4 first-found AO hits, 8 (with 4) reversed traversal order."""
+    lib().orc_set_variant(int(v))
+
+
 def set_threads(n: int):
     lib().orc_set_threads(int(n))
 

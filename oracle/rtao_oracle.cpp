@@ -342,6 +342,15 @@ static float sample_alpha(const AlphaTex& t, V2 uv)
 
 enum QueryMode { Q_AO = 0, Q_SHADOW = 1 };
 
+// Contract-departure switches (tests/test_contract_departures.py only; 0 = the contract the GPU kernels implement).
+//   1  A-Trous: the three per-tap quotients as IEEE divisions (rtao_atrous.comp:99,103 spell `/`) instead of reciprocal multiplies
+//   2  A-Trous: every fetch through its sampler at the COMPUTED uv (rtao_atrous.comp:55-56,80-89: LINEAR for the AO image,
+//      NEAREST for depth / normal at clamp(uv + offset)) instead of an exact texel fetch
+//   4  queryAoClosestHit: gl_RayFlagsTerminateOnFirstHitEXT taken literally -- the first ACCEPTED candidate in traversal order
+//      ends the query (rtao_trace_half.comp:131-139,176-181), instead of the closest committed hit
+//   8  with 4: the other traversal order (children / triangles visited in reverse), a second legal driver behaviour
+static int g_variant = 0;
+
 struct Hit { float t; uint32_t tri; float u, v; };
 
 // Candidate filter of queryAoClosestHit (rtao_trace_half.comp:141-175).
@@ -396,6 +405,8 @@ static bool query(Scene& s, V3 o, V3 d, float tmin, float tmax, QueryMode mode, 
     uint32_t best_flat = 0xffffffffu, best_tri = 0xffffffffu;
     float bu = 0, bv = 0;
     bool found = false;
+    const bool first_found = (g_variant & 4) != 0 && !tie && centre_dir == nullptr;   // AO queries only (not the G-buffer producer)
+    const bool reverse = first_found && (g_variant & 8) != 0;
     auto test = [&](uint32_t ti) -> bool {
         const Tri& tr = s.tris[ti];
         float t, u, v;
@@ -415,11 +426,12 @@ static bool query(Scene& s, V3 o, V3 d, float tmin, float tmax, QueryMode mode, 
             if (!ao_confirm(s, tr, cu, cv)) return false;
         }
         tbest = t; best_flat = tr.flat; best_tri = ti; bu = u; bv = v; found = true;
-        return mode == Q_SHADOW;  // any-hit terminates
+        return mode == Q_SHADOW || (first_found && mode == Q_AO);  // any-hit terminates
     };
     if (s.brute || s.nodes.empty()) {
-        for (uint32_t i = 0; i < s.tris.size(); ++i)
-            if (test(i)) break;
+        const uint32_t nt = (uint32_t)s.tris.size();
+        for (uint32_t i = 0; i < nt; ++i)
+            if (test(reverse ? nt - 1u - i : i)) break;
     } else {
         float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;
         int stack[128];
@@ -440,7 +452,10 @@ static bool query(Scene& s, V3 o, V3 d, float tmin, float tmax, QueryMode mode, 
             if (n.left < 0) {
                 uint32_t first = (uint32_t)(-n.left - 1);
                 for (uint32_t i = 0; i < (uint32_t)n.right; ++i)
-                    if (test(s.order[first + i])) { done = true; break; }
+                    if (test(s.order[first + (reverse ? (uint32_t)n.right - 1u - i : i)])) { done = true; break; }
+            } else if (reverse) {
+                stack[sp++] = n.right;
+                stack[sp++] = n.left;
             } else {
                 stack[sp++] = n.left;
                 stack[sp++] = n.right;
@@ -767,11 +782,28 @@ static void atrous_pixel(const float* ubo, int W, int H, int stepIn, const uint1
     const float invSigmaAbs = 1.0f / sigmaAbs, invSigmaRel = 1.0f / sigmaRel;
     float stepScale = 1.0f + 0.25f * (float)step;                              // :104
     const float invZden = 1.0f / gmax(centerZ, 1e-3f);
+    const bool v_div = (g_variant & 1) != 0, v_samp = (g_variant & 2) != 0;
+    const Img16 srcImg{src, W, H}, depthImg{depth, W, H};
+    const float invSizeX = 1.0f / (float)W, invSizeY = 1.0f / (float)H;       // :55
+    const float uvx = ((float)px + 0.5f) * invSizeX, uvy = ((float)py + 0.5f) * invSizeY;   // :56
+    if (v_samp) {                                                              // centre through the samplers at uv (:62-72)
+        center = tex_linear_r(srcImg, uvx, uvy);
+        centerZ = gmax(tex_nearest_r(depthImg, uvx, uvy), 1e-3f);
+        centerN = decodeNormalSafe(normal, W, iclamp((int)floorf(uvx * (float)W), 0, W - 1), iclamp((int)floorf(uvy * (float)H), 0, H - 1));
+    }
     for (int y = -2; y <= 2; ++y) {                                            // :78-112
         for (int x = -2; x <= 2; ++x) {
             int tx = iclamp(px + x * step, 0, W - 1), ty = iclamp(py + y * step, 0, H - 1);  // :80-81
             size_t to = (size_t)ty * W + tx;
             float sv = half_to_float(src[to]);                                 // :82-89
+            if (v_samp) {
+                const float tu = gclamp(uvx + ((float)x * (float)step) * invSizeX, 0.0f, 1.0f);   // :80-81
+                const float tv = gclamp(uvy + ((float)y * (float)step) * invSizeY, 0.0f, 1.0f);
+                sv = tex_linear_r(srcImg, tu, tv);
+                tx = iclamp((int)floorf(tu * (float)W), 0, W - 1);             // NEAREST texel of depth / normal at tapUv
+                ty = iclamp((int)floorf(tv * (float)H), 0, H - 1);
+                to = (size_t)ty * W + tx;
+            }
             float spatial = det_exp(-0.5f * (float)(x * x + y * y));           // :90
             float range = det_exp(-fabsf(sv - center) * 8.0f);                 // :91
             float tapZ = gmax(half_to_float(depth[to]), 1e-3f);                // :92-93
@@ -779,8 +811,8 @@ static void atrous_pixel(const float* ubo, int W, int H, int stepIn, const uint1
             float dz = fabsf(tapZ - centerZ);                                  // :98
             // GLSL `/` may be a reciprocal multiply (2.5 ULP); the contract takes that form for the three
             // per-tap quotients, with the reciprocals correctly rounded
-            float dzRel = dz * invZden;                                        // :99
-            float depthNorm = gmax(dz * invSigmaAbs, dzRel * invSigmaRel);     // :103
+            float dzRel = v_div ? dz / gmax(centerZ, 1e-3f) : dz * invZden;    // :99
+            float depthNorm = v_div ? gmax(dz / sigmaAbs, dzRel / sigmaRel) : gmax(dz * invSigmaAbs, dzRel * invSigmaRel);   // :103
             depthNorm *= stepScale;                                            // :104
             float depthWeight = det_exp(-depthNorm * depthNorm);               // :105
             float normalWeight = pow32(gclamp(dot3(centerN, tapN), 0.0f, 1.0f));  // :107
@@ -953,6 +985,9 @@ void orc_stats(void* sp, uint64_t out[3], int reset)
     out[0] = s->n_rays.load(); out[1] = s->n_nodes.load(); out[2] = s->n_tris.load();
     if (reset) { s->n_rays = 0; s->n_nodes = 0; s->n_tris = 0; }
 }
+
+void orc_set_variant(int v) { g_variant = v; }
+int orc_get_variant() { return g_variant; }
 
 void orc_set_threads(int n)
 {
