@@ -286,7 +286,7 @@ VKR_DI void resolve_pixel(const FrameParams& fp, const Img16& depth, const Img16
 template <bool STATS>
 __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp, const uint16_t* depthP,
                                                     const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
-                                                    int y0, int y1, uint32_t tiles_x, float4* rayBuf,
+                                                    int y0, int y1, uint32_t tiles_x, uint32_t tile_base, float4* rayBuf,
                                                     unsigned long long* stats)
 {
     __shared__ uint32_t s_stack[2 * VKR_LDS_STACK * K1_BLOCK];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
     uint32_t* stack = s_stack + threadIdx.x;
     constexpr int B = K1_BLOCK;
 
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = tile_base + blockIdx.x;   // the ray slice is indexed by blockIdx.x alone: launches of a frame reuse it
     const int lane = threadIdx.x;
     const int px = (int)(tile % tiles_x) * 8 + (lane & 7);
     const int py = y0 + (int)(tile / tiles_x) * 8 * fp.stripeMul + (lane >> 3);
@@ -1066,20 +1066,30 @@ hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* 
         return s ? VKR_Q(true, 6) : VKR_Q(false, 6);
 #undef VKR_Q
     }
-    // ray buffer: one slice per wave of the launch, sized for the current rays/px (grow-only, so steady-state
-    // frames allocate nothing)
-    size_t need = (size_t)n_tiles * ((size_t)fp.rayCount * 64u * 2u + (size_t)fp.rayCount * 16u);
+    // One ray per lane (VKR_TRACE_MODE=lane, or a tree too large for the queue items).  Ray buffer: one slice per wave of a
+    // launch (grow-only, so steady-state frames allocate nothing); the frame is cut into launches of at most
+    // K1_LANE_SCRATCH_BYTES of slices, so the scratch stays bounded at any resolution (one launch up to ~1080p at 8 rays).
+    const size_t slice_f4 = (size_t)fp.rayCount * 64u * 2u + (size_t)fp.rayCount * 16u;
+    const size_t K1_LANE_SCRATCH_BYTES = 256u << 20;
+    uint32_t per_launch = (uint32_t)(K1_LANE_SCRATCH_BYTES / (slice_f4 * sizeof(float4)));
+    if (per_launch < 1u) per_launch = 1u;
+    if (per_launch > n_tiles) per_launch = n_tiles;
+    const size_t need = (size_t)per_launch * slice_f4;
     if (c->d_raybuf.n < need) {
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
         if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
     }
-    if (c->stats_enabled)
-        k_trace<true><<<n_tiles, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
-                                                   c->d_raybuf.p, c->d_stats.p);
-    else
-        k_trace<false><<<n_tiles, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x,
-                                                    c->d_raybuf.p, nullptr);
-    return hipGetLastError();
+    for (uint32_t base = 0; base < n_tiles; base += per_launch) {
+        const uint32_t nb = (n_tiles - base < per_launch) ? n_tiles - base : per_launch;
+        if (c->stats_enabled)
+            k_trace<true><<<nb, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, base,
+                                                  c->d_raybuf.p, c->d_stats.p);
+        else
+            k_trace<false><<<nb, K1_BLOCK, 0, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, base,
+                                                   c->d_raybuf.p, nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------
