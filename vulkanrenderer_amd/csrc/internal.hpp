@@ -179,6 +179,7 @@ inline SceneDev scene_dev(const vkr_ctx* c)
     s.nodes = c->d_nodes.p;
     s.tris = c->d_tris.p;
     s.tri_count = c->has_bvh ? c->tri_count : 0;
+    s.node_count = c->has_bvh ? c->wide_count : 0;
     s.lut = c->d_lut.p;
     s.indices = c->d_indices.p;
     s.uvs = c->d_uvs.p;

@@ -602,6 +602,15 @@ VKR_DI float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1,
 VKR_DI float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 VKR_DI float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// -DVKR_DEBUG_BOUNDS: every LDS queue / ray / global-stack index of k_trace_q is checked on the device; a violation sets a bit
+// in stats[23] (read back by vkr_trace_stats_get under VKR_PHASE_DUMP) and the index is forced to 0, so the run stays in
+// bounds and reports instead of faulting.  (Round 1 recorded an undiagnosed GPU fault of a 7-waves-per-SIMD build.)
+#ifdef VKR_DEBUG_BOUNDS
+#define VKR_BOUND(IDX, LIMIT, CODE) (((uint32_t)(IDX) < (uint32_t)(LIMIT)) ? (uint32_t)(IDX) : (atomicOr((unsigned int*)&stats[23], (unsigned int)(CODE)), 0u))
+#else
+#define VKR_BOUND(IDX, LIMIT, CODE) (IDX)
+#endif
+
 struct NodeIn { float4 a, b, q0, q1, q2, q3; uint32_t rayhi; };   // one popped node item with its operands in flight
 
 template <bool STATS, int RB>
@@ -692,7 +701,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 float tMinRay;
                 make_ray(pc, rayCount, i, &rayOrigin, &rayDir, &tMinRay);
                 const uint32_t k = (uint32_t)i * nvalid + rank;
-                s_ra[k] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
+                s_ra[VKR_BOUND(k, RAYS, 1)] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
                 s_rb[k] = make_float4(safe_rcp(rayDir.x), safe_rcp(rayDir.y), safe_rcp(rayDir.z), pc.radius);   // tMax = radius (:430)
                 g_dir[k] = make_float4(rayDir.x, rayDir.y, rayDir.z, tMinRay);
             }
@@ -712,8 +721,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
             // ---------------- alpha step: MASK candidates (:163-173), n items from s_aq[base..]
             auto alpha_step = [&](uint32_t n, uint32_t base) {
                 if ((uint32_t)lane < n) {
-                    const uint32_t it = s_aq[base + (uint32_t)lane];
-                    const uint32_t tri = it & PMASK, ray = it >> SH;
+                    const uint32_t it = s_aq[VKR_BOUND(base + (uint32_t)lane, K1_AQ, 2)];
+                    const uint32_t tri = VKR_BOUND(it & PMASK, sc.tri_count, 4), ray = VKR_BOUND(it >> SH, RAYS, 8);
                     const float4 a = s_ra[ray], d = g_dir[ray];
                     const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
                     const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                         uint32_t m = (uint32_t)K1_LQ - lq;
                         if (m > glq) m = glq;
                         glq -= m;
-                        for (uint32_t j = (uint32_t)lane; j < m; j += 64u) s_lq[lq + j] = g_lq[glq + j];
+                        for (uint32_t j = (uint32_t)lane; j < m; j += 64u) s_lq[VKR_BOUND(lq + j, K1_LQ, 16)] = g_lq[VKR_BOUND(glq + j, K1_GLQ, 32)];
                         lq += m;
                         continue;
                     }
@@ -750,7 +759,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                             if (m > gnq) m = gnq;
                             if (m > (uint32_t)K1_NQ - nq) m = (uint32_t)K1_NQ - nq;
                             gnq -= m;
-                            for (uint32_t j = (uint32_t)lane; j < m; j += 64u) s_nq[nq + j] = g_nq[gnq + j];
+                            for (uint32_t j = (uint32_t)lane; j < m; j += 64u) s_nq[VKR_BOUND(nq + j, K1_NQ, 64)] = g_nq[VKR_BOUND(gnq + j, K1_GNQ, 128)];
                             nq += m;
                         }
                     } else if (next < set_size) {
@@ -760,7 +769,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                         if (m > (uint32_t)K1_NQ - nq) m = (uint32_t)K1_NQ - nq;
                         for (uint32_t j = (uint32_t)lane; j < m; j += 64u) {
                             const uint32_t ray = round ? retry_list[next + j] : next + j;
-                            s_nq[nq + j] = ray << SH;   // root = node 0
+                            s_nq[VKR_BOUND(nq + j, K1_NQ, 256)] = VKR_BOUND(ray, RAYS, 512) << SH;   // root = node 0
                             if (STATS) nrays++;
                         }
                         nq += m; next += m;
@@ -777,8 +786,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const uint32_t n = lq < 64u ? lq : 64u;
                     lq -= n;
                     const bool act = (uint32_t)lane < n;
-                    const uint32_t it = act ? s_lq[lq + (uint32_t)lane] : 0u;      // item 0: ray 0, triangle 0 (valid addresses)
-                    const uint32_t ray = it >> SH, pl = it & PMASK;
+                    const uint32_t it = act ? s_lq[VKR_BOUND(lq + (uint32_t)lane, K1_LQ, 1024)] : 0u;      // item 0: ray 0, triangle 0 (valid addresses)
+                    const uint32_t ray = VKR_BOUND(it >> SH, RAYS, 2048), pl = VKR_BOUND(it & PMASK, 2u * sc.tri_count, 4096);
                     const uint32_t cntT = act ? (pl & 1u) + 1u : 0u;
                     const uint32_t toff = (pl & ~1u) * 24u;                        // first triangle * 48 bytes
                     const float4 a = s_ra[ray], d = g_dir[ray];
@@ -809,7 +818,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
         /* a time (accepting a hit later only delays pruning; the minimum is the same) */                           \
         const unsigned long long cm = __ballot(cand);                                                               \
         if (cm != 0ull) {                                                                                           \
-            if (cand) s_aq[aq + mbcnt64(cm)] = (ray << SH) | ((pl >> 1) + (uint32_t)(J));                           \
+            if (cand) s_aq[VKR_BOUND(aq + mbcnt64(cm), K1_AQ, 8192)] = (ray << SH) | ((pl >> 1) + (uint32_t)(J));                           \
             aq += (uint32_t)__popcll(cm);                                                                           \
             if (aq >= 64u) { aq -= 64u; VKR_STAMP(3) alpha_step(64u, aq); if (STATS) ph_n[2]++; VKR_STAMP(4) }      \
         }                                                                                                           \
@@ -837,7 +846,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 // side effects) and are masked out of the hit tests by an exit distance below any entry distance.
                 auto fetch = [&](uint32_t it) -> NodeIn {
                     NodeIn in;
-                    const uint32_t ray = it >> SH, node = it & PMASK;
+                    const uint32_t ray = VKR_BOUND(it >> SH, RAYS, 16384), node = VKR_BOUND(it & PMASK, sc.node_count, 32768);
                     const float4* np = (const float4*)(node_base + ((size_t)node << 6));
                     in.q0 = np[0]; in.q1 = np[1]; in.q2 = np[2]; in.q3 = np[3];
                     in.a = s_ra[ray]; in.b = s_rb[ray];
@@ -889,21 +898,21 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const uint32_t totn = (cn0 + cn1) + (cn2 + cn3), totl = (cl0 + cl1) + (cl2 + cl3);
                     if (nq + totn <= (uint32_t)K1_NQ && lq + totl <= (uint32_t)K1_LQ) {
                         // everything fits in LDS (the common case): eight predicated stores, no further checks
-                        if (h0 && !l0) s_nq[nq + mbcnt64(mn0)] = rayhi | r0;
+                        if (h0 && !l0) s_nq[VKR_BOUND(nq + mbcnt64(mn0), K1_NQ, 1u << 17)] = rayhi | r0;
                         if (h0 && l0) s_lq[lq + mbcnt64(ml0)] = rayhi_leaf + r0;
                         if (h1 && !l1) s_nq[nq + cn0 + mbcnt64(mn1)] = rayhi | r1;
                         if (h1 && l1) s_lq[lq + cl0 + mbcnt64(ml1)] = rayhi_leaf + r1;
                         if (h2 && !l2) s_nq[nq + (cn0 + cn1) + mbcnt64(mn2)] = rayhi | r2;
                         if (h2 && l2) s_lq[lq + (cl0 + cl1) + mbcnt64(ml2)] = rayhi_leaf + r2;
-                        if (h3 && !l3) s_nq[nq + (totn - cn3) + mbcnt64(mn3)] = rayhi | r3;
-                        if (h3 && l3) s_lq[lq + (totl - cl3) + mbcnt64(ml3)] = rayhi_leaf + r3;
+                        if (h3 && !l3) s_nq[VKR_BOUND(nq + (totn - cn3) + mbcnt64(mn3), K1_NQ, 1u << 18)] = rayhi | r3;
+                        if (h3 && l3) s_lq[VKR_BOUND(lq + (totl - cl3) + mbcnt64(ml3), K1_LQ, 1u << 19)] = rayhi_leaf + r3;
                         nq += totn; lq += totl;
                     } else {
                         // rare: per slot, LDS while it fits, the wave's global stack beyond
 #define VKR_PUSH(SQ, QN, CAP, GQ, GN, PRED, MASK, PC, ITEM)                                                         \
     {                                                                                                               \
         if (QN + (PC) <= (uint32_t)(CAP)) { if (PRED) SQ[QN + mbcnt64(MASK)] = (ITEM); QN += (PC); }                \
-        else { if (PRED) GQ[GN + mbcnt64(MASK)] = (ITEM); GN += (PC); if (STATS) nspill += (lane == 0) ? (PC) : 0u; } \
+        else { if (PRED) GQ[VKR_BOUND(GN + mbcnt64(MASK), (GQ == g_nq ? K1_GNQ : K1_GLQ), 1u << 20)] = (ITEM); GN += (PC); if (STATS) nspill += (lane == 0) ? (PC) : 0u; } \
     }
                         VKR_PUSH(s_nq, nq, K1_NQ, g_nq, gnq, h0 && !l0, mn0, cn0, rayhi | r0)
                         VKR_PUSH(s_lq, lq, K1_LQ, g_lq, glq, h0 && l0, ml0, cl0, rayhi_leaf + r0)
@@ -917,7 +926,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     }
                 };
                 const bool act0 = (uint32_t)lane < n, act1 = (uint32_t)lane + 64u < n;
-                const uint32_t it0 = act0 ? s_nq[nq + (uint32_t)lane] : 0u;
+                const uint32_t it0 = act0 ? s_nq[VKR_BOUND(nq + (uint32_t)lane, K1_NQ, 65536)] : 0u;
                 const NodeIn in0 = fetch(it0);
                 if (K1_STEP > 64u && n > 64u) {                                     // wave-uniform
                     const uint32_t it1 = act1 ? s_nq[nq + 64u + (uint32_t)lane] : 0u;
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     }
                     const unsigned long long m = __ballot(need);
                     if (need) {
-                        retry_list[nretry + mbcnt64(m)] = k;
+                        retry_list[VKR_BOUND(nretry + mbcnt64(m), RAYS, 1u << 21)] = k;
                         const float4 d = g_dir[k];
                         const float adv = gmax(a.w * 2.0f, 2e-4f);                  // :194-196
                         const V3 ro = V3{a.x, a.y, a.z} + V3{d.x, d.y, d.z} * adv;
@@ -1040,7 +1049,13 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     if (c->d_tile_counter.n < 16u * 8u && (e = c->d_tile_counter.alloc(16u * 8u)) != hipSuccess) return e;   // 8 counters, 64 B apart
     if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 16u * 8u * 4u, st)) != hipSuccess) return e;
     k_trace_q<STATS, RB><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, n_items,
-                                                        c->d_raybuf.p, c->d_tile_counter.p, STATS ? c->d_stats.p : nullptr);
+                                                        c->d_raybuf.p, c->d_tile_counter.p,
+#ifdef VKR_DEBUG_BOUNDS
+                                                        c->d_stats.p
+#else
+                                                        STATS ? c->d_stats.p : nullptr
+#endif
+                                                        );
     return hipGetLastError();
 }
 

@@ -56,6 +56,7 @@ struct SceneDev {
     const float4* nodes;
     const float4* tris;
     uint32_t tri_count;
+    uint32_t node_count;
     // MASK path (rtao_trace_half.comp:141-175)
     const uint2* lut;           // InstanceLUTEntry {materialID, indexBufferOffset}
     const uint32_t* indices;    // merged, global vertex ids

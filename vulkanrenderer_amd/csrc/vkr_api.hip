@@ -934,7 +934,7 @@ int vkr_trace_stats_get(vkr_ctx* c, vkr_trace_stats* out, int reset)
         static const char* names[8] = {"setup_raygen", "inject", "node_steps", "leaf_steps", "alpha_steps", "retry_list", "resolve", "tile_pull"};
         fprintf(stderr, "{\"k1_phase_cycles\": {");
         for (int k = 0; k < 8; ++k) fprintf(stderr, "\"%s\": %llu, ", names[k], h[8 + k]);
-        fprintf(stderr, "\"n_node_steps\": %llu, \"n_leaf_steps\": %llu, \"n_alpha_steps\": %llu, \"node_items\": %llu, \"waves\": %llu, \"spilled_items\": %llu}}\n", h[16], h[17], h[18], h[19], h[20], h[5]);
+        fprintf(stderr, "\"n_node_steps\": %llu, \"n_leaf_steps\": %llu, \"n_alpha_steps\": %llu, \"node_items\": %llu, \"waves\": %llu, \"spilled_items\": %llu, \"bound_violation_bits\": %llu}}\n", h[16], h[17], h[18], h[19], h[20], h[5], h[23]);
     }
     out->overflow_tiles = h[5];
     out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
