@@ -266,6 +266,22 @@ VKR_API int vkr_rtao_image(vkr_ctx* ctx, uint32_t which, uint16_t** out);
 VKR_API int vkr_shadow_sun(vkr_ctx* ctx, const float* world_pos, const float* geom_normal, const uint8_t* valid,
                            uint32_t pixel_count, const float light_dir_to_light[3], float sun_radius,
                            float sample_count, float* out_vis, void* stream);
+/* No counterpart in the reference: vkr_shadow_sun for callers that cannot allocate -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Same inputs, same outputs, same bits as vkr_shadow_sun (its packet
+ * kernels), but the scratch those kernels need (the chunk counter of the persistent waves and the frame's sample-direction
+ * table, which vkr_shadow_sun keeps in buffers it allocates on first use) lives in a fixed device array of
+ * VKR_NOALLOC_SCRATCH_BYTES inside the library (each GPU the library runs on holds it until the process ends); the call
+ * performs no hipMalloc / hipFree and calls no allocating routine.
+ * Limits (VKR_ERR_LIMIT, nothing is launched): pixel_count <= VKR_NOALLOC_MAX_PIXELS; the BVH must fit the packet
+ * kernel's queue items (<= 2^22 wide nodes; larger trees: vkr_shadow_sun).
+ * Every call on a GPU -- from any context of that device -- shares that GPU's array: calls that overlap on one GPU race;
+ * issue them on one stream or order them with events. */
+#define VKR_NOALLOC_SCRATCH_BYTES 1024
+#define VKR_NOALLOC_MAX_PIXELS (1u << 28)
+#define VKR_NOALLOC_MAX_DEVICES 64
+VKR_API int vkr_shadow_sun_noalloc(vkr_ctx* ctx, const float* world_pos, const float* geom_normal, const uint8_t* valid,
+                                   uint32_t pixel_count, const float light_dir_to_light[3], float sun_radius,
+                                   float sample_count, float* out_vis, void* stream);
 /* Replaces: ComputeShadowVisibility (pbr.frag:169-196), one light. */
 VKR_API int vkr_shadow_point(vkr_ctx* ctx, const float* world_pos, const float* geom_normal, const uint8_t* valid,
                              uint32_t pixel_count, const float light_pos[3], float* out_vis, void* stream);

@@ -113,6 +113,7 @@ SYMBOLS = {
     "vkr_rtao_reset": (C.c_int, [_P, _P]),
     "vkr_rtao_image": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
     "vkr_shadow_sun": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), C.c_float, C.c_float, _P, _P]),
+    "vkr_shadow_sun_noalloc": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), C.c_float, C.c_float, _P, _P]),
     "vkr_shadow_point": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), _P, _P]),
     "vkr_gbuffer_primary": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P]),
     "vkr_gbuffer_primary_msaa": (C.c_int, [_P, C.POINTER(C.c_float), C.c_uint32, _P, _P, _P, _P, _P, _P]),

@@ -213,6 +213,9 @@ hipError_t fill_r16f_launch(uint16_t* img, size_t count, float value, hipStream_
 // shadow_kernels.hip
 hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
                              const float L[3], float radius, float samples, float* out, hipStream_t st);
+hipError_t noalloc_scratch_init(int device);
+hipError_t shadow_sun_noalloc_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
+                                     const float L[3], float radius, float samples, float* out, hipStream_t st);
 hipError_t shadow_point_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
                                const float P[3], float* out, hipStream_t st);
 hipError_t gbuffer_launch(vkr_ctx* c, const FrameParams& fp, uint16_t* depth, uint16_t* normal, float* wp, float* ng,

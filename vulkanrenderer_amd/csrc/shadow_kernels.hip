@@ -1,6 +1,7 @@
 // shadow_kernels.hip -- K4 sun-disc Poisson shadow rays, K5 point-light shadow ray (pbr.frag:169-260 lifted from
 // per-fragment to per-pixel), and the primary-ray G-buffer producer that stands in for DepthPrepass.
 #include "internal.hpp"
+#include <mutex>
 
 namespace vkr {
 
@@ -921,6 +922,60 @@ hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const
     }
     k_shadow_sun<<<(count + VKR_TRACE_BLOCK - 1) / VKR_TRACE_BLOCK, VKR_TRACE_BLOCK, 0, st>>>(
         scene_dev(c), wp, ng, valid, count, V3{L[0], L[1], L[2]}, radius, samples, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// vkr_shadow_sun_noalloc: the packet form of the sun shadows for callers that cannot allocate (HIP graph capture, tight
+// serving loops).  Its scratch -- the chunk counter of the persistent waves and the frame's SunFrame, which
+// vkr_shadow_sun keeps in two buffers it hipMallocs on first use -- lives in a file-scope device array instead.
+//   * `scratch` is a host-side stand-in, not a device address: the address each GPU holds its copy at comes from
+//     hipGetSymbolAddress, once per device, at vkr_create (noalloc_scratch_init), and only that pointer is ever passed
+//     to kernels or hipMemsetAsync.
+//   * Every call on a GPU shares that GPU's array (all contexts of the device): the counter is cleared and the SunFrame
+//     rewritten at the start of every call, and calls that overlap on one GPU race -- serialise them.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t NOALLOC_COUNTER_OFF = 0, NOALLOC_FRAME_OFF = 256;
+static_assert(NOALLOC_FRAME_OFF + sizeof(SunFrame) <= VKR_NOALLOC_SCRATCH_BYTES, "scratch holds the counter slot and one SunFrame");
+static __device__ __align__(256) unsigned char scratch[VKR_NOALLOC_SCRATCH_BYTES];
+static void* g_noalloc_scratch[VKR_NOALLOC_MAX_DEVICES] = {};    // per device: where that GPU holds `scratch`
+static std::mutex g_noalloc_mutex;
+
+hipError_t noalloc_scratch_init(int device)      // called by vkr_create with `device` current
+{
+    if (device < 0 || device >= VKR_NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (g_noalloc_scratch[device]) return hipSuccess;
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_noalloc_scratch[device] = p;
+    return hipSuccess;
+}
+
+hipError_t shadow_sun_noalloc_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
+                                     const float L[3], float radius, float samples, float* out, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    void* base = (c->device >= 0 && c->device < VKR_NOALLOC_MAX_DEVICES) ? g_noalloc_scratch[c->device] : nullptr;
+    if (!base) return hipErrorNotInitialized;
+    uint32_t* counter = (uint32_t*)((unsigned char*)base + NOALLOC_COUNTER_OFF);
+    SunFrame* sf = (SunFrame*)((unsigned char*)base + NOALLOC_FRAME_OFF);
+    hipError_t e;
+    ShadowArgs sa{wp, ng, valid, count, V3{L[0], L[1], L[2]}, radius, samples, V3{0, 0, 0}, out, nullptr};
+    if ((e = hipMemsetAsync(counter, 0, 256, st)) != hipSuccess) return e;      // the last call left its chunk count here
+    k_sun_setup<<<1, 64, 0, st>>>(sa.L, radius, samples, sf);
+    int per_cu = 0;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    if (c->sun_reserve_waves > 0) per_cu = per_cu > c->sun_reserve_waves ? per_cu - c->sun_reserve_waves : 1;
+    uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
+    uint32_t pix = (uint32_t)SP_PIX;                      // same chunking as shadow_sun_launch
+    while (pix > 64u && (count + pix - 1u) / pix < 4u * blocks) pix >>= 1;
+    const uint32_t n_chunks = (count + pix - 1u) / pix;
+    if (blocks > n_chunks) blocks = n_chunks;
+    k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, counter);
     return hipGetLastError();
 }
 

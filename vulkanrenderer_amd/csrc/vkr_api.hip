@@ -135,6 +135,8 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
         return code;
     };
     if ((e = hipSetDevice(c->device)) != hipSuccess) return bail(VKR_ERR_HIP, "hipSetDevice", e);
+    // where this GPU holds the fixed scratch array of vkr_shadow_sun_noalloc (hipGetSymbolAddress, once per device)
+    if ((e = noalloc_scratch_init(c->device)) != hipSuccess) return bail(VKR_ERR_HIP, "scratch symbol address", e);
     size_t px = (size_t)c->W * c->H;
     for (int i = 0; i < 2; ++i) {
         if ((e = c->d_hist_img[i].alloc(px)) != hipSuccess) return bail(VKR_ERR_OOM, "history image", e);
@@ -874,6 +876,25 @@ int vkr_shadow_sun(vkr_ctx* c, const float* world_pos, const float* geom_normal,
     if (int rc = set_device(c)) return rc;
     HIP_OR_FAIL(c, shadow_sun_launch(c, world_pos, geom_normal, valid, pixel_count, L, sun_radius, sample_count, out_vis,
                                      (hipStream_t)stream));
+    return VKR_OK;
+}
+
+int vkr_shadow_sun_noalloc(vkr_ctx* c, const float* world_pos, const float* geom_normal, const uint8_t* valid,
+                           uint32_t pixel_count, const float L[3], float sun_radius, float sample_count, float* out_vis,
+                           void* stream)
+{
+    if (!c) return VKR_ERR_INVALID_ARG;
+    if (!world_pos || !geom_normal || !L || !out_vis) return fail(c, VKR_ERR_INVALID_ARG, "vkr_shadow_sun_noalloc: NULL argument");
+    if (!c->has_bvh) return fail(c, VKR_ERR_STATE, "vkr_shadow_sun_noalloc before vkr_bvh_build");
+    if (pixel_count > VKR_NOALLOC_MAX_PIXELS)
+        return fail(c, VKR_ERR_LIMIT, "vkr_shadow_sun_noalloc: %u pixels exceed the maximum of %u (split the call, or use vkr_shadow_sun)",
+                    pixel_count, VKR_NOALLOC_MAX_PIXELS);
+    if (c->wide_count > (1u << vkr::KQ_NODE_BITS))
+        return fail(c, VKR_ERR_LIMIT, "vkr_shadow_sun_noalloc: the BVH has %u wide nodes, the packet kernel's items hold 2^%u (use vkr_shadow_sun)",
+                    c->wide_count, vkr::KQ_NODE_BITS);
+    if (int rc = set_device(c)) return rc;
+    HIP_OR_FAIL(c, shadow_sun_noalloc_launch(c, world_pos, geom_normal, valid, pixel_count, L, sun_radius, sample_count, out_vis,
+                                             (hipStream_t)stream));
     return VKR_OK;
 }
 
