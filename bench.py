@@ -286,6 +286,13 @@ def main_c2(args):
     print(json.dumps(out))
 
 
+def _hip_runtime():
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return hip
+
+
 def main():
     args = parse_args()
     if args.workload == "c1":
@@ -368,6 +375,27 @@ def main():
     gathered = torch.zeros((n, 2, hb, W), dtype=torch.int16, device=dev)
     sun16 = torch.zeros((H, W), dtype=torch.float16, device=dev)
 
+    # VKR_BENCH_CAPI_COMM=1: the same schedule with both gathers behind the C boundary (vkr_comm_attach + vkr_rtao_gather_history
+    # + vkr_gather_bands: fused pack, ncclAllGather on the frame's stream, fused unpack) -- what a C++ host would run.  Under
+    # RCCL the process group's own communicator is attached; in the gloo rehearsal the custom-transport hook carries it.
+    capi_comm = n > 1 and os.environ.get("VKR_BENCH_CAPI_COMM") == "1"
+    if capi_comm:
+        if rehearse:
+            def gloo_allgather(user, send, recv, nbytes, stream):
+                torch.cuda.synchronize()
+                h_in = torch.empty(nbytes, dtype=torch.uint8)
+                h_out = torch.empty(n * nbytes, dtype=torch.uint8)
+                hip = _hip_runtime()
+                if hip.hipMemcpy(h_in.data_ptr(), send, nbytes, 2) != 0:
+                    return 1
+                dist.all_gather_into_tensor(h_out, h_in)
+                return hip.hipMemcpy(recv, h_out.data_ptr(), n * nbytes, 1)
+            ctx.attachCommCustom(gloo_allgather, rank, n)
+        else:
+            dist.barrier()                                                       # the communicator exists after the first collective
+            backend = dist.distributed_c10d._get_default_group()._get_backend(dev)
+            ctx.attachComm(int(backend._comm_ptr()), rank, n)
+
     pending = []   # the [rtao_full | sun] gather of the previous frame, still in flight on the communicator's stream
 
     def finish_output_gather():
@@ -403,6 +431,20 @@ def main():
                 issue_sun(i, None)                                             # queued behind K1: K1 holds the CUs until it drains
                 join_sun()
                 ev_sun_read.record(torch.cuda.current_stream())
+            return
+        if capi_comm:
+            rpass.traceStripes(ubos[i], rank, n)
+            if shadows is not None:
+                issue_sun(i, (y0, y1))
+            rpass.gatherHistory()
+            planes = [rpass.rtao_full]
+            if shadows is not None:
+                join_sun()
+                sun16[y0:y1].copy_(shadows.sun_vis[y0:y1])
+                ev_sun_read.record(torch.cuda.current_stream())
+                planes.append(sun16.view(torch.int16))
+            rpass.denoiseBand(ubos[i], y0, y1)
+            ctx.gatherBands(planes)
             return
         rpass.traceStripes(ubos[i], rank, n)                                  # overlaps the previous frame's output gather
         if shadows is not None:
@@ -473,7 +515,8 @@ def main():
                                + (f", sharded over {n} GPUs (K1: interleaved 8-row stripes, A-Trous/sun: row bands) + 2 RCCL all-gathers/frame" if n > 1 else ""),
                    "triangles": info.triangle_count, "instances": int(len(scene.instance_mesh)),
                    "bvh_levels": info.height, "bvh_nodes": info.node_count, "binary_height": info.binary_height, "lbvh_build_ms": build_ms,
-                   "rays_per_frame": total_rays / K, "parallelism": f"rowband{n}" if n > 1 else "single"},
+                   "rays_per_frame": total_rays / K, "parallelism": f"rowband{n}" if n > 1 else "single",
+                   "collective": ("none" if n == 1 else "c-abi (vkr_gather_*)" if capi_comm else "torch.distributed all_gather")},
     }
 
     if rank == 0 and not args.no_extra and n > 1:

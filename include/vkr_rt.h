@@ -43,7 +43,8 @@ typedef enum vkr_status {
     VKR_ERR_STATE = 2,       /* call order (e.g. trace before bvh_build)          */
     VKR_ERR_HIP = 3,         /* a HIP runtime call failed; see vkr_last_error()   */
     VKR_ERR_OOM = 4,         /* device allocation failed                          */
-    VKR_ERR_LIMIT = 5        /* a fixed capacity was exceeded (stack depth, ...)  */
+    VKR_ERR_LIMIT = 5,       /* a fixed capacity was exceeded (stack depth, ...)  */
+    VKR_ERR_RCCL = 6         /* the attached communicator / all-gather reported an error */
 } vkr_status;
 
 typedef struct vkr_ctx vkr_ctx;
@@ -232,6 +233,29 @@ VKR_API int vkr_rtao_execute_band(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uin
  * without rows still flips its frame index).  Bit-identical to vkr_rtao_execute on the same inputs. */
 VKR_API int vkr_rtao_trace_stripes(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t rank, uint32_t nranks, void* stream);
 VKR_API int vkr_rtao_denoise_band(vkr_ctx* ctx, const vkr_rtao_frame_io* io, uint32_t y0, uint32_t y1, void* stream);
+
+/* The collective of that schedule, behind the boundary (no reference counterpart; SURVEY 8b proposed ABI, 8e "one collective
+ * per exchange").  A C++ host attaches its communicator once per context:
+ *   vkr_comm_attach         an RCCL communicator (ncclComm_t passed as void*; borrowed, must outlive the context or be
+ *                           detached with nccl_comm = NULL).  librccl.so is resolved with dlopen at this call, the library
+ *                           does not link it.  rank / n_ranks are checked against ncclCommUserRank / ncclCommCount.
+ *   vkr_comm_attach_custom  the host's own transport (MPI, gloo, a test harness): fn(user, send, recv, bytes, stream) must
+ *                           leave rank r's `bytes` bytes at recv + r * bytes on every rank, ordered on `stream`
+ *                           (device pointers; return 0 for success).  fn = NULL detaches.
+ * and then calls, per frame, on the stream of the frame:
+ *   vkr_rtao_trace_stripes(rank, n) -> vkr_rtao_gather_history -> vkr_rtao_denoise_band(rows of rank) -> vkr_gather_bands
+ * vkr_rtao_gather_history: all ranks end up with every row of history[curr] of the frame in flight (one fused pack kernel
+ *   of this rank's stripes, ONE all-gather of raw bytes, one fused unpack kernel).
+ * vkr_gather_bands: planes[k] are full-frame R16F (or any 16-bit) images on the device of which this rank has produced the
+ *   rows [rank*Hb, min(H,(rank+1)*Hb)), Hb = ceil(H / n_ranks) -- rtao_full, and e.g. a 16-bit sun-visibility plane; after
+ *   the call every rank holds all rows of all planes (pack, ONE all-gather, unpack).  1 <= n_planes <= VKR_GATHER_MAX_PLANES.
+ * Errors: VKR_ERR_STATE without an attached communicator, VKR_ERR_RCCL when the transport fails. */
+#define VKR_GATHER_MAX_PLANES 4
+typedef int (*vkr_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+VKR_API int vkr_comm_attach(vkr_ctx* ctx, void* nccl_comm, uint32_t rank, uint32_t n_ranks);
+VKR_API int vkr_comm_attach_custom(vkr_ctx* ctx, vkr_allgather_fn fn, void* user, uint32_t rank, uint32_t n_ranks);
+VKR_API int vkr_rtao_gather_history(vkr_ctx* ctx, void* stream);
+VKR_API int vkr_gather_bands(vkr_ctx* ctx, uint16_t* const* planes_r16f, uint32_t n_planes, void* stream);
 /* history[curr] of the frame in flight (the image dispatchTrace writes; device pointer, R16F W*H). */
 VKR_API int vkr_rtao_history_curr(vkr_ctx* ctx, uint16_t** out);
 

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VKR_LIB_PATH: experiment hook (tools/variants.sh) to load a differently-built copy of the same library
 LIB_PATH = os.environ.get("VKR_LIB_PATH") or os.path.join(_HERE, "lib", "libvkr_rt.so")
 
-VKR_OK, VKR_ERR_INVALID_ARG, VKR_ERR_STATE, VKR_ERR_HIP, VKR_ERR_OOM, VKR_ERR_LIMIT = range(6)
+VKR_OK, VKR_ERR_INVALID_ARG, VKR_ERR_STATE, VKR_ERR_HIP, VKR_ERR_OOM, VKR_ERR_LIMIT, VKR_ERR_RCCL = range(7)
 MAX_MATERIALS = 256
 UBO_FLOATS = 120
 
@@ -88,6 +88,8 @@ class TraceStats(C.Structure):
 
 # every symbol include/vkr_rt.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+# vkr_allgather_fn: int (*)(void* user, const void* send, void* recv, size_t bytes_per_rank, void* stream)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 SYMBOLS = {
     "vkr_create": (C.c_int, [C.POINTER(CreateDesc), C.POINTER(_P)]),
     "vkr_destroy": (None, [_P]),
@@ -112,6 +114,10 @@ SYMBOLS = {
     "vkr_rtao_end_frame": (C.c_int, [_P]),
     "vkr_rtao_reset": (C.c_int, [_P, _P]),
     "vkr_rtao_image": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
+    "vkr_comm_attach": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
+    "vkr_comm_attach_custom": (C.c_int, [_P, ALLGATHER_FN, _P, C.c_uint32, C.c_uint32]),
+    "vkr_rtao_gather_history": (C.c_int, [_P, _P]),
+    "vkr_gather_bands": (C.c_int, [_P, C.POINTER(_P), C.c_uint32, _P]),
     "vkr_shadow_sun": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), C.c_float, C.c_float, _P, _P]),
     "vkr_shadow_sun_noalloc": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), C.c_float, C.c_float, _P, _P]),
     "vkr_shadow_point": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float), _P, _P]),

@@ -166,6 +166,13 @@ struct vkr_ctx {
     uint32_t frame_parity = 0;               // FrameManager currentFrame % 2
     uint32_t last_curr = 0;
 
+    // ---- multi-GPU collective behind the boundary (comm.hip): borrowed RCCL communicator or the host's own all-gather
+    void* comm_nccl = nullptr;
+    vkr_allgather_fn comm_fn = nullptr;
+    void* comm_user = nullptr;
+    uint32_t comm_rank = 0, comm_n = 0;          // comm_n == 0: nothing attached
+    vkr::DevBuf<uint16_t> d_comm_send, d_comm_recv;
+
     // ---- counters
     bool stats_enabled = false;
     vkr::DevBuf<unsigned long long> d_stats; // rays, nodes, tris

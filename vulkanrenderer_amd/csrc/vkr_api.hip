@@ -168,7 +168,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_hist.release(); c->d_digit_totals.release(); c->d_bounds.release(); c->d_height.release();
     c->d_nz.release(); c->d_stats.release(); c->d_raybuf.release();
     c->d_normals.release(); c->d_mesh_has_normals.release(); c->d_graph.release(); c->d_tile_counter.release();
-    c->d_sun_frame.release(); c->d_sun_counter.release(); c->d_shq_raybuf.release(); c->d_shq_counter.release();
+    c->d_sun_frame.release(); c->d_sun_counter.release(); c->d_shq_raybuf.release(); c->d_shq_counter.release(); c->d_comm_send.release(); c->d_comm_recv.release();
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
     c->d_ib_infos.release(); c->d_ib_bounds.release(); c->d_ib_flags.release(); c->d_ib_tile.release();
     c->d_ib_counters.release(); c->d_ib_seg_begin.release(); c->d_ib_seg_rank.release(); c->d_ib_spans.release();

@@ -14,7 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import time
 from dataclasses import dataclass
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -122,6 +122,22 @@ class Context:
 
     def sync(self):
         _check(self.handle, self.lib.vkr_sync(self.handle, self.stream()), "vkr_sync")
+
+    # the collective of the row-band schedule behind the C boundary (comm.hip; include/vkr_rt.h "multi-GPU")
+    def attachComm(self, nccl_comm: int, rank: int, n_ranks: int):
+        """Attach an RCCL communicator (an ncclComm_t as an integer address); 0 detaches."""
+        _check(self.handle, self.lib.vkr_comm_attach(self.handle, C.c_void_p(nccl_comm or None), rank, n_ranks), "vkr_comm_attach")
+
+    def attachCommCustom(self, fn, rank: int, n_ranks: int, user: int = 0):
+        """Attach the host's own all-gather: fn(user, send, recv, bytes_per_rank, stream) -> 0 on success."""
+        self._comm_fn = _capi.ALLGATHER_FN(fn) if fn is not None else _capi.ALLGATHER_FN(0)   # keep the thunk alive
+        _check(self.handle, self.lib.vkr_comm_attach_custom(self.handle, self._comm_fn, C.c_void_p(user or None), rank, n_ranks),
+               "vkr_comm_attach_custom")
+
+    def gatherBands(self, planes: Sequence[torch.Tensor]):
+        """All-gather the contiguous row bands of up to 4 full-frame R16F planes in place (pack + all-gather + unpack)."""
+        arr = (C.c_void_p * len(planes))(*[p.data_ptr() for p in planes])
+        _check(self.handle, self.lib.vkr_gather_bands(self.handle, arr, len(planes), self.stream()), "vkr_gather_bands")
 
 
 class RayTracingContext:
@@ -437,6 +453,11 @@ class RtaoComputePass(RenderPass):
         c = self.ctx
         io = self._io(ubo)
         _check(c.handle, c.lib.vkr_rtao_denoise_band(c.handle, C.byref(io), y0, y1, c.stream()), "vkr_rtao_denoise_band")
+
+    def gatherHistory(self):
+        """All-gather the interleaved history stripes of the frame in flight (between traceStripes and denoiseBand)."""
+        c = self.ctx
+        _check(c.handle, c.lib.vkr_rtao_gather_history(c.handle, c.stream()), "vkr_rtao_gather_history")
 
     def historyCurr(self) -> torch.Tensor:
         """history[curr] of the frame in flight (what dispatchTrace writes), aliasing the library's memory."""
