@@ -567,7 +567,7 @@ def main():
         cal = {}
         try:
             with open(os.path.join(ROOT, "profiles", "r2_k1_valu_model.json")) as f:
-                cal = json.load(f)
+                cal = json.load(f).get(wl_name, {})
         except Exception:
             cal = {}
         # SURVEY 8(d)'s byte figure (8 B/px + 64 B per node visit + 48 B per triangle test): bytes served by L1/L2, NOT HBM
@@ -580,18 +580,28 @@ def main():
                 "cache_side_bytes_per_launch": cache_side, "cache_side_gbs": cache_side / (trace_ms * 1e-3) / 1e9,
                 "compulsory_bytes_per_launch": compulsory,
                 "hbm_frac_compulsory": compulsory / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if cal.get("workload") == wl_name:
-            insts = float(cal["valu_insts_per_launch"])
-            cyc = float(cal["mean_issue_cycles_per_valu_inst"])
+        if cal:
+            # instructions of THIS launch = measured instructions per ray x the rays this launch traced (a rank of an N>1 run
+            # traces its stripes only); peak from the lower-bound price of the mix, so frac <= the true VALU-issue utilisation
+            rays_launch = ao_rays / K
+            insts = float(cal["valu_insts_per_ray"]) * rays_launch
+            cyc = float(cal["mean_issue_cycles_lower"])
             peak = 1024 * 2.4e9 / cyc / 1e9                      # G wave-instructions/s the chip can issue for this mix
             ach = insts / (trace_ms * 1e-3) / 1e9
+            share = rays_launch / float(cal["rays_per_launch"])
+            traffic = float(cal["hbm_bytes_per_launch"]) * share
             roof.update({"bound": "valu", "achieved": ach, "peak": peak, "unit": "G wave-inst/s", "frac": ach / peak,
-                         "traffic": cal.get("hbm_bytes_per_launch"), "traffic_frac_of_hbm_peak": cal.get("hbm_bytes_per_launch", 0.0) / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "td_busy_frac": cal.get("td_busy_frac"), "l1_hit_rate": cal.get("l1_hit_rate"), "l2_hit_rate": cal.get("l2_hit_rate"),
-                         "source": cal.get("source"),
-                         "note": "achieved/peak/frac: VALU issue (the binding resource, DESIGN.md 4).  Instruction count, mix, traffic, TD busy and "
-                                 "hit rates were measured with rocprofv3 --pmc on this workload and are read from the file named in `source`; "
-                                 "launch_ms is this run's HIP-event time.  cache_side_bytes is SURVEY 8(d)'s figure: bytes served by L1/L2, not HBM."})
+                         "frac_estimate": ach / (1024 * 2.4e9 / float(cal["mean_issue_cycles_estimate"]) / 1e9),
+                         "valu_insts_per_launch": insts, "issue_cycles_per_inst": {"lower": cyc, "estimate": cal["mean_issue_cycles_estimate"]},
+                         "traffic": traffic, "traffic_frac_of_hbm_peak": traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "td_busy_frac": cal.get("td_busy_frac"), "ta_busy_frac": cal.get("ta_busy_frac"),
+                         "l1_hit_rate": cal.get("l1_hit_rate"), "l2_hit_rate": cal.get("l2_hit_rate"),
+                         "source": "profiles/r2_k1_valu_model.json <- " + str(cal.get("source")),
+                         "note": "achieved/peak/frac: VALU issue, co-binding with the L1 return path (td_busy_frac), DESIGN.md 4.  peak prices the "
+                                 "instruction classes no counter resolves at the fast class, so frac is a lower bound of the issue utilisation; "
+                                 "frac_estimate prices them by the static mix of the queue loop.  Instructions per ray, mix, traffic, TA/TD busy "
+                                 "and hit rates were measured with rocprofv3 --pmc on this workload (file in `source`), not by this run; launch_ms "
+                                 "and the ray count are this run's.  cache_side_bytes is SURVEY 8(d)'s figure: bytes served by L1/L2, not HBM."})
         else:
             roof.update({"bound": "hbm", "achieved": compulsory / (trace_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": compulsory / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -602,9 +612,10 @@ def main():
         out["roofline_k2"] = {"bound": "hbm", "kernel": f"k_prep + {iters} x k_atrous_tile (K2, upsample folded into the last store)",
                               "achieved": atrous_bytes / (atrous_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": atrous_bytes / (atrous_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "traffic": cal.get("k2_hbm_bytes_per_iteration") if cal.get("workload") == wl_name else None,
+                              "traffic": (cal["k2_hbm_bytes_per_iteration"] * iters) if cal else None,
                               "launch_ms": atrous_ms, "algorithmic_bytes": atrous_bytes,
-                              "source": cal.get("source") if cal.get("workload") == wl_name else None,
+                              "valu_insts": (cal["k2_valu_insts_per_iteration"] * iters) if cal else None,
+                              "source": ("profiles/r2_k1_valu_model.json <- " + str(cal.get("source"))) if cal else None,
                               "note": "VALU-bound by contract: two software exp (bit-exact against the oracle) + pow32 per tap, ~57 "
                                       "instructions x 25 taps per pixel; the v_exp_f32 build (VKR_ATROUS=tol, outside the contract) is timed in DESIGN.md"}
         out["kernels"] = {"trace_ms": trace_ms, "atrous_total_ms": atrous_ms, "upsample_ms": float(np.mean(t_up)),
