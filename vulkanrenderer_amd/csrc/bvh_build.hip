@@ -1077,36 +1077,62 @@ __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bi
                                                     const float4* node_box, const float4* tris, float4* nodes,
                                                     uint4* wide_bref, uint32_t* wide_bin, const BvhBounds* bnd)
 {
+    // Child nodes of one level are numbered in the order of their parents (block-wide exclusive scan, one atomic per block;
+    // blocks reach it roughly in launch order), and the children of a node in Morton order: nodes that are neighbours in
+    // space are neighbours in memory on every level, so the node fetches of a wave of coherent rays fall into few
+    // 128-byte lines (the L1 return path charges a wave-level load by the distinct lines it touches, tools/calib/l1_rate2).
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_base;
     const uint32_t begin = ctl->level_begin, end = ctl->level_end;
-    uint32_t w = begin + blockIdx.x * 256u + threadIdx.x;
-    if (w >= end) return;
-    int b = (int)wide_bin[w];
-    int cand[4];
-    int ncand = 2;
-    { int2 c = bin_child[b]; cand[0] = c.x; cand[1] = c.y; cand[2] = 0; cand[3] = 0; }
+    const uint32_t w = begin + blockIdx.x * 256u + threadIdx.x;
+    const bool live = w < end;
+    int cand[4] = {0, 0, 0, 0};
+    int ncand = 0;
     auto tri_count = [&](int c) -> uint32_t {
         if (c < 0) return 1u;
         uint2 r = bin_range[c];
         return r.y - r.x + 1u;
     };
-    for (int round = 0; round < 2; ++round) {
-        int pick = -1;
-        float best = -1.0f;
-        for (int k = 0; k < ncand; ++k) {
-            int c = cand[k];
-            if (c < 0 || tri_count(c) <= (uint32_t)VKR_LEAF_MAX) continue;
+    if (live) {
+        int b = (int)wide_bin[w];
+        int2 c0 = bin_child[b];
+        cand[0] = c0.x; cand[1] = c0.y;
+        ncand = 2;
+        for (int round = 0; round < 2; ++round) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int k = 0; k < ncand; ++k) {
+                int c = cand[k];
+                if (c < 0 || tri_count(c) <= (uint32_t)VKR_LEAF_MAX) continue;
 #ifdef VKR_COLLAPSE_BY_COUNT
-            float a = (float)tri_count(c);
+                float a = (float)tri_count(c);
 #else
-            float a = half_area(node_box[(size_t)c * 2], node_box[(size_t)c * 2 + 1]);
+                float a = half_area(node_box[(size_t)c * 2], node_box[(size_t)c * 2 + 1]);
 #endif
-            if (a > best) { best = a; pick = k; }
+                if (a > best) { best = a; pick = k; }
+            }
+            if (pick < 0) break;
+            int2 c = bin_child[cand[pick]];
+            for (int k = ncand; k > pick + 1; --k) cand[k] = cand[k - 1];     // keep the slots in Morton (left to right) order
+            cand[pick] = c.x;
+            cand[pick + 1] = c.y;
+            ++ncand;
         }
-        if (pick < 0) break;
-        int2 c = bin_child[cand[pick]];
-        cand[pick] = c.x;
-        cand[ncand++] = c.y;
     }
+    uint32_t nint = 0;
+    for (int k = 0; k < ncand; ++k) nint += (cand[k] >= 0 && tri_count(cand[k]) > (uint32_t)VKR_LEAF_MAX) ? 1u : 0u;
+    s_scan[threadIdx.x] = nint;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        uint32_t v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 255u) s_base = atomicAdd(&ctl->count, s_scan[255]);
+    __syncthreads();
+    if (!live) return;
+    uint32_t next = s_base + s_scan[threadIdx.x] - nint;
     float4* node = nodes + (size_t)w * 4;
     write_wide_boxes(node, cand, ncand, node_box, tris, pad_abs_of(bnd));
     uint32_t ref[4], bref[4];
@@ -1119,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bi
             bref[k] = (uint32_t)c;
             uint32_t cnt = tri_count(c);
             if (c >= 0 && cnt > (uint32_t)VKR_LEAF_MAX) {
-                uint32_t idx = atomicAdd(&ctl->count, 1u);
+                uint32_t idx = next++;
                 wide_bin[idx] = (uint32_t)c;
                 ref[k] = idx;
             } else {
