@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
-            out[k][r["Counter_Name"]].append((d + ":" + r["Dispatch_Id"], float(r["Counter_Value"])))   # one pass = one directory
+            out[k][r["Counter_Name"]].append((f + ":" + r["Dispatch_Id"], float(r["Counter_Value"])))   # one pass = one directory
 for k, cs in out.items():
     print(k)
     for c, vals in sorted(cs.items()):

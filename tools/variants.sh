@@ -13,10 +13,10 @@ for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
   names+=($name)
   ( bd=/tmp/vkr_variant_$name; mkdir -p $bd
-    for f in vkr_api bvh_build rtao_kernels shadow_kernels indirect_build ibl_kernels; do
+    for f in vkr_api bvh_build rtao_kernels shadow_kernels indirect_build ibl_kernels comm; do
       /opt/rocm/bin/hipcc $BASE $flags -I$SRC -c $SRC/$f.hip -o $bd/$f.o &
     done; wait
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUTD/libvkr_$name.so $bd/*.o ) 2>&1 | grep -E "error" || true
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUTD/libvkr_$name.so $bd/*.o -ldl ) 2>&1 | grep -E "error" || true
 done
 cmd=""
 for n in "${names[@]}"; do

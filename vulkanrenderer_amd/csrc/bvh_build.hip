@@ -1084,6 +1084,7 @@ __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bi
     __shared__ uint32_t s_scan[256];
     __shared__ uint32_t s_base;
     const uint32_t begin = ctl->level_begin, end = ctl->level_end;
+    if (begin + blockIdx.x * 256u >= end) return;             // block-uniform: the launch is sized for the widest level
     const uint32_t w = begin + blockIdx.x * 256u + threadIdx.x;
     const bool live = w < end;
     int cand[4] = {0, 0, 0, 0};

@@ -559,13 +559,19 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #define K1_STEP 64u        // node items per step: 64 (one per lane) or 128 (two per lane)
 #endif
 #ifndef K1_NQ
-#define K1_NQ 512          // node queue entries in LDS
+#define K1_NQ 320          // node queue entries in LDS (320 + 192 + 128 entries + 44 B x 128 rays = 8 KB: 20 workgroups per CU)
+#endif
+#ifndef K1_DIR_LDS
+#define K1_DIR_LDS 0       // 1: ray directions in LDS (12 B per ray) instead of the wave's global slice -- measured slower (3.06 vs 2.90 ms)
+#endif
+#ifndef K1_LEAF_AT
+#define K1_LEAF_AT 64u     // a leaf step runs as soon as this many leaf items wait (a full wave)
 #endif
 #ifndef K1_SLABS
 #define K1_SLABS 8         // work counters: 1 = one row-major list, 8 = one vertical slab of tile columns per XCD
 #endif
 #ifndef K1_LQ
-#define K1_LQ 256          // leaf queue entries in LDS (>= 64; a node step's leaf pushes beyond it go to the global stack)
+#define K1_LQ 192          // leaf queue entries in LDS (>= 64; a node step's leaf pushes beyond it go to the global stack)
 #endif
 constexpr uint32_t K1_GNQ = 4096;      // node-item overflow stack per wave (global)
 constexpr uint32_t K1_GLQ = 512;       // leaf-item overflow per wave (global): one node step pushes <= 4 * 128
@@ -585,7 +591,7 @@ __host__ __device__ inline QSliceLayout q_slice_layout(int rb)
 }
 __host__ __device__ inline size_t q_lds_bytes(int rb)
 {
-    return (size_t)(1u << rb) * 32u + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u;
+    return (size_t)(1u << rb) * (K1_DIR_LDS ? 44u : 32u) + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u;
 }
 // pixels per work item: the largest power of two <= 64 with P * rayCount <= 2^RB
 __host__ __device__ inline int q_item_pixels(int rb, int rayCount)
@@ -624,7 +630,12 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     extern __shared__ float4 smem4[];
     float4* s_ra = smem4;                                     // [RAYS] origin.xyz | tMin        (round 1: advanced origin | tMin')
     float4* s_rb = smem4 + RAYS;                              // [RAYS] 1/direction | closest hit so far (float bits)
+#if K1_DIR_LDS
+    float* s_rd = (float*)(smem4 + 2u * RAYS);                // [RAYS][3] direction (leaf steps, alpha tests, retry)
+    uint32_t* s_nq = (uint32_t*)(s_rd + 3u * RAYS);           // node items
+#else
     uint32_t* s_nq = (uint32_t*)(smem4 + 2u * RAYS);          // node items
+#endif
     uint32_t* s_lq = s_nq + K1_NQ;                            // leaf items
     uint32_t* s_aq = s_lq + K1_LQ;                            // MASK candidates: ray << SH | triangle
 
@@ -703,7 +714,12 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 const uint32_t k = (uint32_t)i * nvalid + rank;
                 s_ra[VKR_BOUND(k, RAYS, 1)] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
                 s_rb[k] = make_float4(safe_rcp(rayDir.x), safe_rcp(rayDir.y), safe_rcp(rayDir.z), pc.radius);   // tMax = radius (:430)
+#if K1_DIR_LDS
+                s_rd[3u * k] = rayDir.x; s_rd[3u * k + 1u] = rayDir.y; s_rd[3u * k + 2u] = rayDir.z;
+                ((float*)&g_dir[k])[3] = tMinRay;                       // tMin as generated: read back by the resolve only
+#else
                 g_dir[k] = make_float4(rayDir.x, rayDir.y, rayDir.z, tMinRay);
+#endif
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -718,12 +734,21 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
             const uint32_t set_size = (round == 0) ? total : nretry;
             if (set_size == 0) break;
             uint32_t next = 0, nq = 0, lq = 0, aq = 0, gnq = 0, glq = 0;      // wave-uniform
+            auto ray_dir = [&](uint32_t ray) -> V3 {
+#if K1_DIR_LDS
+                return V3{s_rd[3u * ray], s_rd[3u * ray + 1u], s_rd[3u * ray + 2u]};
+#else
+                const float4 d4 = g_dir[ray];
+                return V3{d4.x, d4.y, d4.z};
+#endif
+            };
             // ---------------- alpha step: MASK candidates (:163-173), n items from s_aq[base..]
             auto alpha_step = [&](uint32_t n, uint32_t base) {
                 if ((uint32_t)lane < n) {
                     const uint32_t it = s_aq[VKR_BOUND(base + (uint32_t)lane, K1_AQ, 2)];
                     const uint32_t tri = VKR_BOUND(it & PMASK, sc.tri_count, 4), ray = VKR_BOUND(it >> SH, RAYS, 8);
-                    const float4 a = s_ra[ray], d = g_dir[ray];
+                    const float4 a = s_ra[ray];
+                    const V3 d = ray_dir(ray);
                     const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
                     const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
                     float u, v, t;
@@ -737,7 +762,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
             // needs attention?", then a step.  Refills from the wave's global overflow stack and the throttled step width
             // are the rare paths.
             for (;;) {
-                bool do_leaf = lq >= 64u;
+                bool do_leaf = lq >= K1_LEAF_AT;
                 if (!do_leaf && (nq < K1_STEP || (glq | gnq) != 0u)) {
                     if (glq > 0u) {
                         // ---------------- leaf items back from the global stack (before anything else pushes leaves)
@@ -790,7 +815,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const uint32_t ray = VKR_BOUND(it >> SH, RAYS, 2048), pl = VKR_BOUND(it & PMASK, 2u * sc.tri_count, 4096);
                     const uint32_t cntT = act ? (pl & 1u) + 1u : 0u;
                     const uint32_t toff = (pl & ~1u) * 24u;                        // first triangle * 48 bytes
-                    const float4 a = s_ra[ray], d = g_dir[ray];
+                    const float4 a = s_ra[ray];
+                    const V3 d = ray_dir(ray);
                     const float tbest0 = s_rb[ray].w;
                     const float4* tp = (const float4*)(tri_base + toff);
                     const float4 ta0 = tp[0], tb0 = tp[1], tc0 = tp[2];
@@ -849,6 +875,10 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const uint32_t ray = VKR_BOUND(it >> SH, RAYS, 16384), node = VKR_BOUND(it & PMASK, sc.node_count, 32768);
                     const float4* np = (const float4*)(node_base + ((size_t)node << 6));
                     in.q0 = np[0]; in.q1 = np[1]; in.q2 = np[2]; in.q3 = np[3];
+#ifdef VKR_EXP_EXTRA_LOAD   // experiment: what one more 16-byte load per node visit costs (sensitivity to the L1 return path)
+                    { float4 ex; asm volatile("global_load_dwordx4 %0, %1, off offset:32\n s_waitcnt vmcnt(0)" : "=v"(ex) : "v"(np) : "memory");
+                      in.q3.x = u2f(f2u(in.q3.x) | (f2u(ex.x) & 0u)); }
+#endif
                     in.a = s_ra[ray]; in.b = s_rb[ray];
                     in.rayhi = it & ~PMASK;
                     return in;
@@ -861,6 +891,12 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     if (STATS) { if (act) { cnt.nodes++; if ((int)(__ffsll((long long)__ballot(act)) - 1) == lane) cnt.wave_node_iters++; } }
                     const float tmin = in.a.w;
                     const V3 id = V3{in.b.x, in.b.y, in.b.z};
+#ifdef VKR_EXP_EXTRA_VALU   // experiment: what N more slow-class VALU instructions per node step cost (sensitivity to VALU issue)
+                    { float dmy = tb;
+#pragma unroll
+                      for (int e_ = 0; e_ < VKR_EXP_EXTRA_VALU; ++e_) asm volatile("v_max_f32 %0, %0, %0" : "+v"(dmy));
+                      asm volatile("" :: "v"(dmy)); }
+#endif
                     // Slab tests straight on the quantised planes: plane = fma(q, s, o), t = (plane - ro) * id is evaluated
                     // as fma(q, s*id, (o - ro)*id): one fma per plane.  The direction sign picks the near/far byte quads
                     // once per axis; unused slots are stored inverted and miss by themselves.  Rounding of this form is
@@ -954,7 +990,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const unsigned long long m = __ballot(need);
                     if (need) {
                         retry_list[VKR_BOUND(nretry + mbcnt64(m), RAYS, 1u << 21)] = k;
-                        const float4 d = g_dir[k];
+                        const V3 d = ray_dir(k);
                         const float adv = gmax(a.w * 2.0f, 2e-4f);                  // :194-196
                         const V3 ro = V3{a.x, a.y, a.z} + V3{d.x, d.y, d.z} * adv;
                         s_ra[k] = make_float4(ro.x, ro.y, ro.z, gmax(a.w, 1e-4f));
@@ -1046,8 +1082,9 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
         if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
     }
-    if (c->d_tile_counter.n < 16u * 8u && (e = c->d_tile_counter.alloc(16u * 8u)) != hipSuccess) return e;   // 8 counters, 64 B apart
-    if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, 16u * 8u * 4u, st)) != hipSuccess) return e;
+    constexpr uint32_t n_ctr = 16u * (K1_SLABS > 8 ? K1_SLABS : 8);                                              // counters 64 B apart
+    if (c->d_tile_counter.n < n_ctr && (e = c->d_tile_counter.alloc(n_ctr)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, n_ctr * 4u, st)) != hipSuccess) return e;
     k_trace_q<STATS, RB><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, n_items,
                                                         c->d_raybuf.p, c->d_tile_counter.p,
 #ifdef VKR_DEBUG_BOUNDS
