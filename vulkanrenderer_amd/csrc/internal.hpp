@@ -162,6 +162,8 @@ struct vkr_ctx {
     int atrous_mode = 1;                     // K2 form: 1 LDS-tiled (default), 0 per-pixel gathers (VKR_ATROUS=gather), 2 tiled + v_exp_f32 (VKR_ATROUS=tol, outside the bit-exact contract)
     bool trace_streaming = true;             // K1 form: wave-wide queues (k_trace_q) or one ray per lane (k_trace)
     int num_cus = 0;
+    vkr::DevBuf<float4> d_pixctx;            // K1_SPLIT: 3 float4 per pixel from k_pix_setup (rtao_kernels.hip)
+    vkr::DevBuf<float2> d_vis;               // K1_SPLIT: summed visibility + hit bits per pixel, k_trace_q -> k_pix_resolve
     vkr::DevBuf<float4> d_nz;                // per-frame decoded normal.xyz + clamped depth (A-Trous operand)
     uint32_t frame_parity = 0;               // FrameManager currentFrame % 2
     uint32_t last_curr = 0;

@@ -564,6 +564,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #ifndef K1_DIR_LDS
 #define K1_DIR_LDS 0       // 1: ray directions in LDS (12 B per ray) instead of the wave's global slice -- measured slower (3.06 vs 2.90 ms)
 #endif
+#ifndef K1_SPLIT
+#define K1_SPLIT 1         // 1: per-pixel setup and temporal resolve run as their own full-occupancy kernels around k_trace_q
+#endif
 #ifndef K1_LEAF_AT
 #define K1_LEAF_AT 64u     // a leaf step runs as soon as this many leaf items wait (a full wave)
 #endif
@@ -617,12 +620,55 @@ VKR_DI float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v
 #define VKR_BOUND(IDX, LIMIT, CODE) (IDX)
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// K1_SPLIT: the per-pixel parts of the pass as streaming kernels of their own.  Inside k_trace_q an item is 16 pixels on 64
+// lanes, so main():237-400 and :433-471 ran at a quarter of the lanes and held a persistent wave for 11 % of its time
+// (VKR_PHASE_DUMP); here they run one pixel per lane at full occupancy.  Record per pixel (3 float4):
+//   [0] worldPos.xyz | viewZ if the pixel casts rays, else 0      [1] geomNormal.xyz | radius      [2] bias, footprint, cos, sin
+// Rows: the launch's stripes, row j of the launch = image row y0 + (j / 8) * 8 * stripeMul + j % 8 (k_trace_q's tiles).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pix_setup(FrameParams fp, const uint16_t* depthP, uint16_t* histCurr, uint32_t* hitMask,
+                                                   int y0, int y1, int rows, float4* pixctx)
+{
+    const int px = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63u);
+    const int j = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    const int py = y0 + (j >> 3) * 8 * fp.stripeMul + (j & 7);
+    if (px >= fp.W || j >= rows || py >= y1) return;
+    const Img16 depth{depthP, fp.W, fp.H};
+    PixelCtx pc;
+    setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);
+    float4* o = pixctx + 3u * ((size_t)py * fp.W + px);
+    o[0] = make_float4(pc.worldPos.x, pc.worldPos.y, pc.worldPos.z, pc.valid ? pc.viewZ : 0.0f);
+    if (pc.valid) {
+        o[1] = make_float4(pc.geomNormal.x, pc.geomNormal.y, pc.geomNormal.z, pc.radius);
+        o[2] = make_float4(pc.bias, pc.footprint, pc.cs, pc.sn);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pix_resolve(FrameParams fp, const uint16_t* depthP, const uint16_t* histPrevP, uint16_t* histCurr,
+                                                     uint32_t* hitMask, int y0, int y1, int rows, const float4* pixctx, const float2* vis)
+{
+    const int px = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63u);
+    const int j = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    const int py = y0 + (j >> 3) * 8 * fp.stripeMul + (j & 7);
+    if (px >= fp.W || j >= rows || py >= y1) return;
+    const size_t o = (size_t)py * fp.W + px;
+    const float4 c0 = pixctx[3u * o];
+    if (!(c0.w > 0.0f)) return;                                 // early-out pixels stored their value in k_pix_setup
+    const Img16 depth{depthP, fp.W, fp.H}, histPrev{histPrevP, fp.W, fp.H};
+    const float2 v = vis[o];
+    PixelCtx pc;
+    pc.viewZ = c0.w; pc.worldPos = V3{c0.x, c0.y, c0.z};
+    resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc, v.x, f2u(v.y));
+}
+
 struct NodeIn { float4 a, b, q0, q1, q2, q3; uint32_t rayhi; };   // one popped node item with its operands in flight
 
 template <bool STATS, int RB>
 __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k_trace_q(
     SceneDev sc, FrameParams fp, const uint16_t* depthP, const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
-    int y0, int y1, uint32_t tiles_x, uint32_t n_items, float4* rayBuf, uint32_t* tile_counter, unsigned long long* stats)
+    int y0, int y1, uint32_t tiles_x, uint32_t n_items, float4* rayBuf, uint32_t* tile_counter, unsigned long long* stats,
+    const float4* pixctx, float2* visOut)
 {
     constexpr uint32_t RAYS = 1u << RB;
     constexpr uint32_t SH = 32u - (uint32_t)RB;              // item = ray << SH | payload
@@ -643,6 +689,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     const int lane = threadIdx.x;
     const int W = fp.W, H = fp.H;
     const Img16 depth{depthP, W, H}, histPrev{histPrevP, W, H};
+    (void)depth; (void)histPrev;
     const QSliceLayout lay = q_slice_layout(RB);
     float4* g_dir = rayBuf + (size_t)blockIdx.x * lay.total_f4;          // [RAYS] direction | tMin as generated
     uint32_t* retry_list = (uint32_t*)(g_dir + lay.dir_f4);
@@ -658,7 +705,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     const uint32_t items_per_block = 64u / (uint32_t)P;       // an 8x8 pixel block is cut into 64 / P items
     // STATS build only: shader cycles (s_memtime) per phase of this wave, summed over waves into stats[8..]
     uint32_t ph_prev = STATS ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
-    uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // setup+raygen, inject/refill, node, leaf, alpha, retry list, resolve, item pull
+    uint32_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // raygen, inject/refill, node, leaf, alpha, retry list, resolve, item pull, setup_pixel, visibility loop
     uint32_t ph_n[4] = {0, 0, 0, 0};             // node steps / leaf steps / alpha steps / node items
 #define VKR_STAMP(K) { if (STATS) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph[K] += now_ - ph_prev; ph_prev = now_; } }
 
@@ -696,10 +743,32 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
         PixelCtx pc;
         pc.valid = false;
         pc.radius = 0.0f; pc.viewZ = 0.0f; pc.worldPos = v3(0, 0, 0);
+#if K1_SPLIT
+        // k_pix_setup ran main():237-400 for every pixel of the launch; what make_ray needs is rebuilt from its record
+        pc.geomNormal = v3(0, 1, 0); pc.origin = v3(0, 0, 0); pc.tT = v3(0, 0, 0); pc.tB = v3(0, 0, 0);
+        pc.bias = 0.0f; pc.footprint = 0.0f; pc.tMin = 0.0f; pc.cs = 1.0f; pc.sn = 0.0f;
+        if (px < W && py < y1) {
+            const float4* cp = pixctx + 3u * ((size_t)py * W + px);
+            const float4 c0 = cp[0];
+            if (c0.w > 0.0f) {
+                const float4 c1 = cp[1], c2 = cp[2];
+                pc.valid = true;
+                pc.worldPos = V3{c0.x, c0.y, c0.z}; pc.viewZ = c0.w;
+                pc.geomNormal = V3{c1.x, c1.y, c1.z}; pc.radius = c1.w;
+                pc.bias = c2.x; pc.footprint = c2.y; pc.cs = c2.z; pc.sn = c2.w;
+                pc.origin = offsetRay(pc.worldPos, pc.geomNormal);                      // :375
+                buildTbn(pc.geomNormal, &pc.tT, &pc.tB);                                // :376
+                pc.tMin = gmax(1e-4f, pc.bias * 0.25f);                                 // :377
+            }
+        }
+#else
         if (px < W && py < y1) setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);   // :233-235
+#endif
+        VKR_STAMP(8)
         const bool valid = pc.valid;
-        const float radius = pc.radius, viewZ = pc.viewZ;     // kept across the queue loop for the resolve: 5 VGPRs
+        const float radius = pc.radius, viewZ = pc.viewZ;     // kept across the queue loop (K1_SPLIT: the radius only)
         const V3 worldPos = pc.worldPos;
+        (void)viewZ; (void)worldPos;
         const unsigned long long pmask = (P == 64) ? ~0ull : ((1ull << P) - 1ull);
         const unsigned long long vmask = __ballot(valid) & pmask;
         const uint32_t nvalid = (uint32_t)__popcll(vmask);
@@ -1029,9 +1098,14 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 }
                 visibility += vis;
             }
+            VKR_STAMP(9)
+#if K1_SPLIT
+            visOut[(size_t)py * W + px] = make_float2(visibility, u2f(mask));      // k_pix_resolve does :433-471
+#else
             PixelCtx pc2;                     // resolve_pixel reads viewZ and worldPos only
             pc2.viewZ = viewZ; pc2.worldPos = worldPos;
             resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc2, visibility, mask);
+#endif
         }
         VKR_STAMP(6)
     }
@@ -1039,6 +1113,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     if (STATS) {
         if (lane == 0) {
             for (int k = 0; k < 8; ++k) atomicAdd(&stats[8 + k], (unsigned long long)ph[k]);
+            atomicAdd(&stats[21], (unsigned long long)ph[8]);
+            atomicAdd(&stats[22], (unsigned long long)ph[9]);
             for (int k = 0; k < 4; ++k) atomicAdd(&stats[16 + k], (unsigned long long)ph_n[k]);
             atomicAdd(&stats[20], 1ull);
             atomicAdd(&stats[5], (unsigned long long)nspill);
@@ -1085,6 +1161,16 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     constexpr uint32_t n_ctr = 16u * (K1_SLABS > 8 ? K1_SLABS : 8);                                              // counters 64 B apart
     if (c->d_tile_counter.n < n_ctr && (e = c->d_tile_counter.alloc(n_ctr)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, n_ctr * 4u, st)) != hipSuccess) return e;
+#if K1_SPLIT
+    const size_t npx = (size_t)fp.W * fp.H;
+    if (c->d_pixctx.n < 3u * npx || c->d_vis.n < npx) {
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        if ((e = c->d_pixctx.alloc(3u * npx)) != hipSuccess || (e = c->d_vis.alloc(npx)) != hipSuccess) return e;
+    }
+    const int rows = (int)tiles_y * 8;
+    const dim3 pgrid(((uint32_t)fp.W + 63u) / 64u, ((uint32_t)rows + 3u) / 4u);
+    k_pix_setup<<<pgrid, 256, 0, st>>>(fp, depth, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p);
+#endif
     k_trace_q<STATS, RB><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, n_items,
                                                         c->d_raybuf.p, c->d_tile_counter.p,
 #ifdef VKR_DEBUG_BOUNDS
@@ -1092,7 +1178,10 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
 #else
                                                         STATS ? c->d_stats.p : nullptr
 #endif
-                                                        );
+                                                        , c->d_pixctx.p, c->d_vis.p);
+#if K1_SPLIT
+    k_pix_resolve<<<pgrid, 256, 0, st>>>(fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p, c->d_vis.p);
+#endif
     return hipGetLastError();
 }
 

@@ -166,7 +166,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_wide_ctl.release(); c->d_wide_bin.release(); c->d_wide_bref.release();
     for (int i = 0; i < 2; ++i) { c->d_keys[i].release(); c->d_vals[i].release(); c->d_hist_img[i].release(); c->d_ping[i].release(); }
     c->d_hist.release(); c->d_digit_totals.release(); c->d_bounds.release(); c->d_height.release();
-    c->d_nz.release(); c->d_stats.release(); c->d_raybuf.release();
+    c->d_nz.release(); c->d_stats.release(); c->d_raybuf.release(); c->d_pixctx.release(); c->d_vis.release();
     c->d_normals.release(); c->d_mesh_has_normals.release(); c->d_graph.release(); c->d_tile_counter.release();
     c->d_sun_frame.release(); c->d_sun_counter.release(); c->d_shq_raybuf.release(); c->d_shq_counter.release(); c->d_comm_send.release(); c->d_comm_recv.release();
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
@@ -952,10 +952,10 @@ int vkr_trace_stats_get(vkr_ctx* c, vkr_trace_stats* out, int reset)
     unsigned long long h[24];
     HIP_OR_FAIL(c, hipMemcpy(h, c->d_stats.p, 192, hipMemcpyDeviceToHost));
     if (getenv("VKR_PHASE_DUMP")) {   // development: per-phase shader cycles of the K1 STATS build, summed over waves (k_trace_q)
-        static const char* names[8] = {"setup_raygen", "inject", "node_steps", "leaf_steps", "alpha_steps", "retry_list", "resolve", "tile_pull"};
+        static const char* names[8] = {"raygen", "inject", "node_steps", "leaf_steps", "alpha_steps", "retry_list", "resolve", "tile_pull"};
         fprintf(stderr, "{\"k1_phase_cycles\": {");
         for (int k = 0; k < 8; ++k) fprintf(stderr, "\"%s\": %llu, ", names[k], h[8 + k]);
-        fprintf(stderr, "\"n_node_steps\": %llu, \"n_leaf_steps\": %llu, \"n_alpha_steps\": %llu, \"node_items\": %llu, \"waves\": %llu, \"spilled_items\": %llu, \"bound_violation_bits\": %llu}}\n", h[16], h[17], h[18], h[19], h[20], h[5], h[23]);
+        fprintf(stderr, "\"n_node_steps\": %llu, \"n_leaf_steps\": %llu, \"n_alpha_steps\": %llu, \"node_items\": %llu, \"waves\": %llu, \"spilled_items\": %llu, \"setup_pixel\": %llu, \"visibility_loop\": %llu, \"bound_violation_bits\": %llu}}\n", h[16], h[17], h[18], h[19], h[20], h[5], h[21], h[22], h[23]);
     }
     out->overflow_tiles = h[5];
     out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
