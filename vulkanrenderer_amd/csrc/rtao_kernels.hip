@@ -567,6 +567,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #ifndef K1_SPLIT
 #define K1_SPLIT 1         // 1: per-pixel setup and temporal resolve run as their own full-occupancy kernels around k_trace_q
 #endif
+#ifndef K1_INJECT
+#define K1_INJECT 64u      // rays injected at the root at a time (when fewer than K1_STEP node items wait)
+#endif
 #ifndef K1_LEAF_AT
 #define K1_LEAF_AT 64u     // a leaf step runs as soon as this many leaf items wait (a full wave)
 #endif
@@ -859,7 +862,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     } else if (next < set_size) {
                         // ---------------- inject the next rays at the root
                         uint32_t m = set_size - next;
-                        if (m > K1_STEP) m = K1_STEP;
+                        if (m > K1_INJECT) m = K1_INJECT;
                         if (m > (uint32_t)K1_NQ - nq) m = (uint32_t)K1_NQ - nq;
                         for (uint32_t j = (uint32_t)lane; j < m; j += 64u) {
                             const uint32_t ray = round ? retry_list[next + j] : next + j;
