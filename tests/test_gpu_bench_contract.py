@@ -28,7 +28,12 @@ def test_bench_json_line_c0():
     r = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # "valu" is what the C3 / C4 lines state (profiles/r2_k1_valu_model.json); C0 has no committed counter model and falls
+    # back to compulsory HBM bytes.  Whatever the bound, it must BE one: frac <= 1.
+    assert r["bound"] in ("hbm", "mfma", "valu") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["frac"] <= 1.0
+    k2 = j["roofline_k2"]
+    assert k2["bound"] == "hbm" and 0.0 < k2["frac"] <= 1.0 and abs(k2["frac"] - k2["achieved"] / k2["peak"]) < 1e-9
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
