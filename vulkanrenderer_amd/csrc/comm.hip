@@ -7,6 +7,7 @@
 // RCCL is resolved with dlopen at attach time, so the library has no link-time dependency on it.
 #include "internal.hpp"
 #include <dlfcn.h>
+#include <mutex>
 
 namespace vkr {
 
@@ -61,9 +62,11 @@ typedef const char* (*fn_errstr_t)(int);
 typedef int (*fn_commint_t)(void*, int*);
 struct RcclApi { void* handle = nullptr; fn_allgather_t all_gather = nullptr; fn_errstr_t err = nullptr; fn_commint_t count = nullptr, user_rank = nullptr; };
 static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;       // contexts on different host threads may attach at the same time
 
 static const char* rccl_load()
 {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle) return nullptr;
     // the copy of RCCL the host process already holds made the communicator: take that one (matched by soname) before
     // loading another; VKR_RCCL_LIB names a path when neither is right
