@@ -947,8 +947,9 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const uint32_t ray = VKR_BOUND(it >> SH, RAYS, 16384), node = VKR_BOUND(it & PMASK, sc.node_count, 32768);
                     const float4* np = (const float4*)(node_base + ((size_t)node << 6));
                     in.q0 = np[0]; in.q1 = np[1]; in.q2 = np[2]; in.q3 = np[3];
-#ifdef VKR_EXP_EXTRA_LOAD   // experiment: what one more 16-byte load per node visit costs (sensitivity to the L1 return path)
-                    { float4 ex; asm volatile("global_load_dwordx4 %0, %1, off offset:32\n s_waitcnt vmcnt(0)" : "=v"(ex) : "v"(np) : "memory");
+#ifdef VKR_EXP_EXTRA_LOAD   // experiment: what one more 16-byte load per node visit costs; the value is its byte offset from the node
+                            // (32 = the q2 quarter again, 64 = the next node's first quarter)
+                    { float4 ex; asm volatile("global_load_dwordx4 %0, %1, off offset:%2\n s_waitcnt vmcnt(0)" : "=v"(ex) : "v"(np), "n"(VKR_EXP_EXTRA_LOAD) : "memory");
                       in.q3.x = u2f(f2u(in.q3.x) | (f2u(ex.x) & 0u)); }
 #endif
                     in.a = s_ra[ray]; in.b = s_rb[ray];
