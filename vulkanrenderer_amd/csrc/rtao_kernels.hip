@@ -550,7 +550,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 //     the step width is throttled only when LDS + global capacity could run out (strict depth-first bound).
 // ---------------------------------------------------------------------------------------------
 #ifndef K1_WAVES
-#define K1_WAVES 5         // resident waves per SIMD the kernel is compiled for (VGPR budget 512 / K1_WAVES)
+#define K1_WAVES 6         // resident waves per SIMD the kernel is compiled for (VGPR budget 512 / K1_WAVES: 80, 2 spilled in the alpha path)
 #endif
 #ifndef K1_RB
 #define K1_RB 7            // ray bits of an item at most: 2^K1_RB rays (32 B of LDS each)
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #define K1_STEP 64u        // node items per step: 64 (one per lane) or 128 (two per lane)
 #endif
 #ifndef K1_NQ
-#define K1_NQ 320          // node queue entries in LDS (320 + 192 + 128 entries + 44 B x 128 rays = 8 KB: 20 workgroups per CU)
+#define K1_NQ 288          // node queue entries in LDS (288 + 128 + 128 entries + 32 B x 128 rays = 6.1 KB: 24 workgroups per CU)
 #endif
 #ifndef K1_DIR_LDS
 #define K1_DIR_LDS 0       // 1: ray directions in LDS (12 B per ray) instead of the wave's global slice -- measured slower (3.06 vs 2.90 ms)
@@ -577,11 +577,12 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #define K1_SLABS 8         // work counters: 1 = one row-major list, 8 = one vertical slab of tile columns per XCD
 #endif
 #ifndef K1_LQ
-#define K1_LQ 192          // leaf queue entries in LDS (>= 64; a node step's leaf pushes beyond it go to the global stack)
+#define K1_LQ 128          // leaf queue entries in LDS (>= 64; a node step's leaf pushes beyond it go to the global stack)
 #endif
 constexpr uint32_t K1_GNQ = 4096;      // node-item overflow stack per wave (global)
 constexpr uint32_t K1_GLQ = 512;       // leaf-item overflow per wave (global): one node step pushes <= 4 * 128
-constexpr uint32_t K1_AQ = 128;        // alpha-test queue (LDS): drained whenever it holds a full wave of candidates
+constexpr uint32_t K1_AQ = 128;        // alpha-test queue (LDS): drained whenever it holds a full wave of candidates (one call site at
+                                       // the top of the loop instead of three inlined copies: no spills at all, but 4 % slower -- measured)
 
 struct QSliceLayout { uint32_t dir_f4, retry_f4, gnq_f4, glq_f4, total_f4; };   // per-wave global scratch, in float4 units
 __host__ __device__ inline QSliceLayout q_slice_layout(int rb)
