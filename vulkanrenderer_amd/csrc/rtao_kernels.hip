@@ -567,6 +567,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #ifndef K1_SPLIT
 #define K1_SPLIT 1         // 1: per-pixel setup and temporal resolve run as their own full-occupancy kernels around k_trace_q
 #endif
+#ifndef K1_EARLY_RETRY
+#define K1_EARLY_RETRY 1   // 1: a self-hit re-traces its ray on the spot (same queue round) instead of in a second round
+#endif
 #ifndef K1_INJECT
 #define K1_INJECT 64u      // rays injected at the root at a time (when fewer than K1_STEP node items wait)
 #endif
@@ -581,8 +584,8 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #endif
 constexpr uint32_t K1_GNQ = 4096;      // node-item overflow stack per wave (global)
 constexpr uint32_t K1_GLQ = 512;       // leaf-item overflow per wave (global): one node step pushes <= 4 * 128
-constexpr uint32_t K1_AQ = 128;        // alpha-test queue (LDS): drained whenever it holds a full wave of candidates (one call site at
-                                       // the top of the loop instead of three inlined copies: no spills at all, but 4 % slower -- measured)
+constexpr uint32_t K1_AQ = 128;        // alpha-test queue (LDS): drained whenever it holds a full wave of candidates (draining at one
+                                       // place only -- loop top or end of the leaf step -- costs 4-7 %: measured twice)
 
 struct QSliceLayout { uint32_t dir_f4, retry_f4, gnq_f4, glq_f4, total_f4; };   // per-wave global scratch, in float4 units
 __host__ __device__ inline QSliceLayout q_slice_layout(int rb)
@@ -598,7 +601,7 @@ __host__ __device__ inline QSliceLayout q_slice_layout(int rb)
 }
 __host__ __device__ inline size_t q_lds_bytes(int rb)
 {
-    return (size_t)(1u << rb) * (K1_DIR_LDS ? 44u : 32u) + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u;
+    return (size_t)(1u << rb) * (K1_DIR_LDS ? 44u : 32u) + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u + (K1_EARLY_RETRY ? 32u : 0u);
 }
 // pixels per work item: the largest power of two <= 64 with P * rayCount <= 2^RB
 __host__ __device__ inline int q_item_pixels(int rb, int rayCount)
@@ -688,6 +691,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
 #endif
     uint32_t* s_lq = s_nq + K1_NQ;                            // leaf items
     uint32_t* s_aq = s_lq + K1_LQ;                            // MASK candidates: ray << SH | triangle
+    uint32_t* s_retry = s_aq + K1_AQ;                         // K1_EARLY_RETRY: one bit per ray, set when it was re-traced (8 words)
+    (void)s_retry;
 
     const int rayCount = fp.rayCount;                         // :252
     const int lane = threadIdx.x;
@@ -787,6 +792,9 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 const uint32_t k = (uint32_t)i * nvalid + rank;
                 s_ra[VKR_BOUND(k, RAYS, 1)] = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, tMinRay);
                 s_rb[k] = make_float4(safe_rcp(rayDir.x), safe_rcp(rayDir.y), safe_rcp(rayDir.z), pc.radius);   // tMax = radius (:430)
+#if K1_EARLY_RETRY
+                ((float*)retry_list)[k] = pc.radius;                    // the ray's tMax again, for its re-trace
+#endif
 #if K1_DIR_LDS
                 s_rd[3u * k] = rayDir.x; s_rd[3u * k + 1u] = rayDir.y; s_rd[3u * k + 2u] = rayDir.z;
                 ((float*)&g_dir[k])[3] = tMinRay;                       // tMin as generated: read back by the resolve only
@@ -795,15 +803,19 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
 #endif
             }
         }
+#if K1_EARLY_RETRY
+        if (lane < 8) s_retry[lane] = 0u;
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         VKR_STAMP(0)
 
         // ------------------------------------------------------------------ phase 2: queues
         const uint32_t total = nvalid * (uint32_t)rayCount;
-        uint32_t retry_mask = 0;     // bit i: this pixel's ray i was re-traced
+        uint32_t retry_mask = 0;     // bit i: this pixel's ray i was re-traced (two-round form)
+        (void)retry_mask;
         uint32_t nretry = 0;
-        for (int round = 0; round < 2; ++round) {
+        for (int round = 0; round < (K1_EARLY_RETRY ? 1 : 2); ++round) {
             const uint32_t set_size = (round == 0) ? total : nretry;
             if (set_size == 0) break;
             uint32_t next = 0, nq = 0, lq = 0, aq = 0, gnq = 0, glq = 0;      // wave-uniform
@@ -815,8 +827,42 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 return V3{d4.x, d4.y, d4.z};
 #endif
             };
+#if K1_EARLY_RETRY
+            // traceAoRay's retry (:193-200) without a second round.  The first query's closest hit is <= 1.5 tMin exactly when SOME
+            // committed hit is (closest hits only get closer), so the lane that commits such a hit re-traces the ray at once: it
+            // claims the ray's bit, rewrites the LDS record (advanced origin, tMin', tMax again) and pushes a root item.  Items of
+            // the ray that are still queued now run against the new record: they only repeat parts of the re-trace (the closest
+            // hit is a minimum, so repeats change nothing).  `trig` lanes have already issued their atomicMin on the old record;
+            // the rewrite comes after it in program order and discards it, as :199 discards the first query's distance.
+            auto retry_now = [&](bool trig, uint32_t ray) {
+                if (__ballot(trig) == 0ull) return;
+                bool win = false;
+                if (trig) {
+                    const uint32_t bit = 1u << (ray & 31u);
+                    win = (atomicOr(&s_retry[ray >> 5], bit) & bit) == 0u;
+                }
+                const unsigned long long wm = __ballot(win);
+                if (wm == 0ull) return;
+                if (win) {
+                    const float4 a = s_ra[ray];
+                    const V3 d = ray_dir(ray);
+                    const float adv = gmax(a.w * 2.0f, 2e-4f);                      // :194-196
+                    const V3 ro = V3{a.x, a.y, a.z} + V3{d.x, d.y, d.z} * adv;
+                    s_ra[ray] = make_float4(ro.x, ro.y, ro.z, gmax(a.w, 1e-4f));
+                    s_rb[ray].w = ((const float*)retry_list)[ray];
+                    if (STATS) nrays++;
+                }
+                const uint32_t cnt = (uint32_t)__popcll(wm);
+                if (nq + cnt <= (uint32_t)K1_NQ) { if (win) s_nq[nq + mbcnt64(wm)] = ray << SH; nq += cnt; }
+                else { if (win) g_nq[VKR_BOUND(gnq + mbcnt64(wm), K1_GNQ, 1u << 22)] = ray << SH; gnq += cnt; if (STATS) nspill += (lane == 0) ? cnt : 0u; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            };
+#endif
             // ---------------- alpha step: MASK candidates (:163-173), n items from s_aq[base..]
             auto alpha_step = [&](uint32_t n, uint32_t base) {
+                bool trig = false;
+                uint32_t tray = 0;
                 if ((uint32_t)lane < n) {
                     const uint32_t it = s_aq[VKR_BOUND(base + (uint32_t)lane, K1_AQ, 2)];
                     const uint32_t tri = VKR_BOUND(it & PMASK, sc.tri_count, 4), ray = VKR_BOUND(it >> SH, RAYS, 8);
@@ -827,9 +873,17 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     float u, v, t;
                     const float tbest = s_rb[ray].w;
                     if (tri_hit(V3{a.x, a.y, a.z}, V3{d.x, d.y, d.z}, ta, tb4, tc, a.w, tbest, &u, &v, &t) &&
-                        alpha_test(sc, f2u(ta.w) & 0x0fffffffu, f2u(tb4.w), u, v))
+                        alpha_test(sc, f2u(ta.w) & 0x0fffffffu, f2u(tb4.w), u, v)) {
                         atomicMin((uint32_t*)&s_rb[ray].w, f2u(t));
+                        trig = t <= a.w * 1.5f;                                     // :193
+                        tray = ray;
+                    }
                 }
+#if K1_EARLY_RETRY
+                retry_now(trig, tray);
+#else
+                (void)trig; (void)tray;
+#endif
             };
             // ---------------- queue loop.  Common path per iteration: one compare for "leaf step?", one for "node queue
             // needs attention?", then a step.  Refills from the wave's global overflow stack and the throttled step width
@@ -891,6 +945,9 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const float4 a = s_ra[ray];
                     const V3 d = ray_dir(ray);
                     const float tbest0 = s_rb[ray].w;
+#if K1_EARLY_RETRY
+                    const uint32_t retried0 = (s_retry[ray >> 5] >> (ray & 31u)) & 1u;
+#endif
                     const float4* tp = (const float4*)(tri_base + toff);
                     const float4 ta0 = tp[0], tb0 = tp[1], tc0 = tp[2];
                     const unsigned long long m2 = __ballot(cntT > 1u);
@@ -925,7 +982,17 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     VKR_LEAF_TRI(0, ta0, tb0, tc0, __ballot(act))
                     if (m2 != 0ull) VKR_LEAF_TRI(1, ta1, tb1, tc1, m2)
 #undef VKR_LEAF_TRI
-                    if (tbest < tbest0) atomicMin((uint32_t*)&s_rb[ray].w, f2u(tbest));   // t > tmin >= 0: bits order like floats
+#if K1_EARLY_RETRY
+                    // An alpha step in the middle of this step may have re-traced this lane's ray (rewritten its record): what the
+                    // lane computed belongs to the old record and is dropped -- the re-trace starts at the root and meets this leaf again.
+                    const bool same_record = ((s_retry[ray >> 5] >> (ray & 31u)) & 1u) == retried0;
+#else
+                    const bool same_record = true;
+#endif
+                    if (tbest < tbest0 && same_record) atomicMin((uint32_t*)&s_rb[ray].w, f2u(tbest));   // t > tmin >= 0: bits order like floats
+#if K1_EARLY_RETRY
+                    retry_now(tbest < tbest0 && tbest <= tmin * 1.5f && same_record, ray); // :193
+#endif
                     if (STATS) ph_n[1]++;
                     VKR_STAMP(3)
                     continue;
@@ -1049,7 +1116,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 if (STATS) { ph_n[0]++; ph_n[3] += n; }
                 VKR_STAMP(2)
             }
-            if (round == 0) {
+            if (!K1_EARLY_RETRY && round == 0) {
                 // rays that ended on a self-hit are traced once more from an advanced origin (:193-200): their LDS records
                 // are rewritten in place (the values every step of round 1 would otherwise recompute)
                 for (int i = 0; i < rayCount; ++i) {
@@ -1092,7 +1159,11 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 const float tmax = radius;
                 float vis = 1.0f;
                 if (tbv < tmax) {                                                   // a hit was committed
+#if K1_EARLY_RETRY
+                    const bool retried = (s_retry[k >> 5] >> (k & 31u)) & 1u;
+#else
                     const bool retried = (retry_mask >> i) & 1u;
+#endif
                     const float adv = gmax(tmin0 * 2.0f, 2e-4f);
                     const float t = retried ? (tbv + adv) : tbv;
                     if (!(t <= tmin0 * 1.5f)) {                                     // :205-212
