@@ -5,7 +5,7 @@ tools/calib/issue_rates*.hip measured on gfx950 (cycles per wave-instruction per
     slow  4.25     max/min/max3/min3/med3, shifts, bfe/bfi/perm/alignbit, every v_cvt, cndmask, v_cmp*, mbcnt, readlane/
                    writelane/readfirstlane, mad_u24, add3, lshl_add/lshl_or/and_or/or3, fma_mix, v_pk_*
     trans 8.2      rcp/rsq/sqrt/exp/log/sin/cos; v_mul_lo/hi_u32 priced here too (quarter rate)
-usage: isa_census.py file.s <mangled-name-prefix> [loop-header-label]
+usage: isa_census.py file.s <mangled-name-prefix> [loop-header-label | depth3]
 Prints JSON: counts for the whole kernel and, when a loop header label (e.g. .LBB5_62) is given, for the lines from
 that label to the last branch back to it (the queue-step loop of k_trace_q).
 """
@@ -72,6 +72,18 @@ def main():
             if ln.startswith(".Lfunc_end"):
                 break
     out = {"kernel": name, "whole_kernel": census(body)}
+    if header == "depth3":     # the largest loop below the outermost one (the queue-step loop of k_trace_q): its header label
+        best = (0, None)
+        for at, ln in enumerate(body):
+            m = re.search(r"Loop Header: Depth=(\d+)", ln)
+            if not m or int(m.group(1)) < 2:
+                continue
+            lab = next(body[i].split(":")[0] for i in range(at, -1, -1) if body[i].startswith(".LBB"))
+            named = [i for i, l2 in enumerate(body) if ("Header=" + lab[2:] + " ") in l2]
+            extent = (max(named) if named else at) - at
+            if extent > best[0]:
+                best = (extent, lab)
+        header = best[1]
     if header:
         start = next(i for i, ln in enumerate(body) if ln.startswith(header + ":"))
         back = [i for i, ln in enumerate(body) if i > start and re.search(r"s_c?branch\w*\s+" + re.escape(header) + r"\b", ln)]
