@@ -232,7 +232,8 @@ static Tree build_ploc(int radius)
 
 static int LEAFMAX = 4;
 // 4-ary collapse: open largest-area child with > LEAFMAX tris, up to twice
-struct WNode { Box cb[4]; int ref[4]; int nch; };   // ref >= 0 wide node, < 0 leaf ~(binary node)
+static int WIDTH = 4;      // env WIDTH=8: 8-ary collapse (open the largest child up to 6 times)
+struct WNode { Box cb[8]; int ref[8]; int nch; };   // ref >= 0 wide node, < 0 leaf ~(binary node)
 struct Wide { std::vector<WNode> w; const Tree* t; };
 static Wide collapse(const Tree& t)
 {
@@ -241,7 +242,7 @@ static Wide collapse(const Tree& t)
         int b = bin[wi]; std::vector<int> ch;
         if (t.n[b].count <= LEAFMAX || t.n[b].l < 0) ch = {b};
         else { ch = {t.n[b].l, t.n[b].r};
-            for (int k = 0; k < 2; ++k) { int bi = -1; float ba = -1;
+            for (int k = 0; k < WIDTH - 2; ++k) { int bi = -1; float ba = -1;
                 for (size_t c = 0; c < ch.size(); ++c) if (t.n[ch[c]].count > LEAFMAX && t.n[ch[c]].l >= 0 && t.n[ch[c]].box.area() > ba) { ba = t.n[ch[c]].box.area(); bi = (int)c; }
                 if (bi < 0) break; int o = ch[bi]; ch[bi] = t.n[o].l; ch.push_back(t.n[o].r); } }
         WNode wn; wn.nch = (int)ch.size();
@@ -325,6 +326,7 @@ int main(int argc, char** argv)
         if (nn.y < 0) nn = nn * -1.f; V3 dd; do { dd = {U(rng) * 2 - 1, U(rng) * 2 - 1, U(rng) * 2 - 1}; } while (dot(dd, dd) > 1 || dot(dd, dd) < 1e-4f); dd = dd * (1.f / std::sqrt(dot(dd, dd))); if (dot(dd, nn) < 0) dd = dd * -1.f;
         ro[i] = p + nn * 1e-3f; rd[i] = dd; }
     float radius = argc > 2 ? atof(argv[2]) : 1.2f;
+    if (getenv("WIDTH")) WIDTH = atoi(getenv("WIDTH"));
     if (argc > 3) LEAFMAX = atoi(argv[3]);
     auto eval = [&](const char* name, const Tree& t) { if (getenv("DP")) { CT = atof(getenv("DP")); Wide W = collapse_dp(t); uint64_t nv = 0, tt = 0; for (int i = 0; i < NR; ++i) trace(W, ro[i], rd[i], radius, nv, tt);
         printf("%-10s DP collapse (ct %.2f): wide nodes %zu  nodes/ray %.2f  tris/ray %.2f\n", name, CT, W.w.size(), (double)nv / NR, (double)tt / NR); fflush(stdout); }
