@@ -567,6 +567,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #ifndef K1_SPLIT
 #define K1_SPLIT 1         // 1: per-pixel setup and temporal resolve run as their own full-occupancy kernels around k_trace_q
 #endif
+#ifndef K1_SELECT_STORES
+#define K1_SELECT_STORES 1  // node-step appends as unpredicated stores with a selected index (see the fast path of the node step)
+#endif
 #ifndef K1_EARLY_RETRY
 #define K1_EARLY_RETRY 1   // 1: a self-hit re-traces its ray on the spot (same queue round) instead of in a second round
 #endif
@@ -586,6 +589,7 @@ constexpr uint32_t K1_GNQ = 4096;      // node-item overflow stack per wave (glo
 constexpr uint32_t K1_GLQ = 512;       // leaf-item overflow per wave (global): one node step pushes <= 4 * 128
 constexpr uint32_t K1_AQ = 128;        // alpha-test queue (LDS): drained whenever it holds a full wave of candidates (draining at one
                                        // place only -- loop top or end of the leaf step -- costs 4-7 %: measured twice)
+constexpr uint32_t K1_TRASH = K1_NQ + K1_LQ + K1_AQ + 8u;   // index (from the node queue) of an LDS word nobody reads: retry bits come first
 
 struct QSliceLayout { uint32_t dir_f4, retry_f4, gnq_f4, glq_f4, total_f4; };   // per-wave global scratch, in float4 units
 __host__ __device__ inline QSliceLayout q_slice_layout(int rb)
@@ -601,7 +605,7 @@ __host__ __device__ inline QSliceLayout q_slice_layout(int rb)
 }
 __host__ __device__ inline size_t q_lds_bytes(int rb)
 {
-    return (size_t)(1u << rb) * (K1_DIR_LDS ? 44u : 32u) + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u + (K1_EARLY_RETRY ? 32u : 0u);
+    return (size_t)(1u << rb) * (K1_DIR_LDS ? 44u : 32u) + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u + 32u + 16u;   // + retry bits + the trash word
 }
 // pixels per work item: the largest power of two <= 64 with P * rayCount <= 2^RB
 __host__ __device__ inline int q_item_pixels(int rb, int rayCount)
@@ -1074,7 +1078,23 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const uint32_t cl0 = (uint32_t)__popcll(ml0), cl1 = (uint32_t)__popcll(ml1), cl2 = (uint32_t)__popcll(ml2), cl3 = (uint32_t)__popcll(ml3);
                     const uint32_t totn = (cn0 + cn1) + (cn2 + cn3), totl = (cl0 + cl1) + (cl2 + cl3);
                     if (nq + totn <= (uint32_t)K1_NQ && lq + totl <= (uint32_t)K1_LQ) {
-                        // everything fits in LDS (the common case): eight predicated stores, no further checks
+                        // everything fits in LDS (the common case)
+#if K1_SELECT_STORES
+                        // One unpredicated store per slot: the lane's queue index is selected (node queue, leaf queue -- which
+                        // follows it in LDS -- or a trash word for a child that was not hit).  Eight `if (hit) queue[..] = item`
+                        // compile to exec-mask save / branch / restore sequences, ~60 scalar instructions per step on the CU's
+                        // one scalar unit (VKR_EXP_EXTRA_SALU: +0.2 % of the launch per scalar instruction per step).
+#define VKR_APPEND(H, L, MN, ML, PREN, PREL, R)                                                                     \
+    {                                                                                                               \
+        const uint32_t in_ = (nq + (PREN)) + mbcnt64(MN), il_ = ((uint32_t)K1_NQ + lq + (PREL)) + mbcnt64(ML);       \
+        s_nq[VKR_BOUND((H) ? ((L) ? il_ : in_) : K1_TRASH, K1_TRASH + 1u, 1u << 17)] = (L) ? rayhi_leaf + (R) : (rayhi | (R)); \
+    }
+                        VKR_APPEND(h0, l0, mn0, ml0, 0u, 0u, r0)
+                        VKR_APPEND(h1, l1, mn1, ml1, cn0, cl0, r1)
+                        VKR_APPEND(h2, l2, mn2, ml2, cn0 + cn1, cl0 + cl1, r2)
+                        VKR_APPEND(h3, l3, mn3, ml3, totn - cn3, totl - cl3, r3)
+#undef VKR_APPEND
+#else
                         if (h0 && !l0) s_nq[VKR_BOUND(nq + mbcnt64(mn0), K1_NQ, 1u << 17)] = rayhi | r0;
                         if (h0 && l0) s_lq[lq + mbcnt64(ml0)] = rayhi_leaf + r0;
                         if (h1 && !l1) s_nq[nq + cn0 + mbcnt64(mn1)] = rayhi | r1;
@@ -1083,6 +1103,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                         if (h2 && l2) s_lq[lq + (cl0 + cl1) + mbcnt64(ml2)] = rayhi_leaf + r2;
                         if (h3 && !l3) s_nq[VKR_BOUND(nq + (totn - cn3) + mbcnt64(mn3), K1_NQ, 1u << 18)] = rayhi | r3;
                         if (h3 && l3) s_lq[VKR_BOUND(lq + (totl - cl3) + mbcnt64(ml3), K1_LQ, 1u << 19)] = rayhi_leaf + r3;
+#endif
                         nq += totn; lq += totl;
                     } else {
                         // rare: per slot, LDS while it fits, the wave's global stack beyond
