@@ -1087,7 +1087,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
 #define VKR_APPEND(H, L, MN, ML, PREN, PREL, R)                                                                     \
     {                                                                                                               \
         const uint32_t in_ = (nq + (PREN)) + mbcnt64(MN), il_ = ((uint32_t)K1_NQ + lq + (PREL)) + mbcnt64(ML);       \
-        s_nq[VKR_BOUND((H) ? ((L) ? il_ : in_) : K1_TRASH, K1_TRASH + 1u, 1u << 17)] = (L) ? rayhi_leaf + (R) : (rayhi | (R)); \
+        /* item: ray | node index, or ray | first * 2 | count - 1 -- a leaf reference is that plus bit 31 */          \
+        s_nq[VKR_BOUND((H) ? ((L) ? il_ : in_) : K1_TRASH, K1_TRASH + 1u, 1u << 17)] = rayhi | ((R) & 0x7fffffffu);   \
     }
                         VKR_APPEND(h0, l0, mn0, ml0, 0u, 0u, r0)
                         VKR_APPEND(h1, l1, mn1, ml1, cn0, cl0, r1)

@@ -331,13 +331,29 @@ VKR_DI f2v pk_fma(f2v a, float b, float c) { return __builtin_elementwise_fma(a,
 
 // Moeller-Trumbore exactly as in k_trace / traverse<>() (operation order is part of the numeric contract): no culling,
 // t strictly inside (tmin, tbest).
+// 1.0f / x, correctly rounded like the IEEE division the compiler would emit (v_div_scale, v_rcp, 4 x v_fma, v_div_fmas,
+// v_div_fixup), in three instructions where that is proven: v_rcp_f32 + one fma Newton step gives the same bits for EVERY
+// float with biased exponent 1..252 (exhaustive check over all 2^32 inputs on gfx950: tools/calib/rcp_exact.hip,
+// profiles/r2_rcp_exact.json); denormals, zeros, infinities, NaNs and |x| >= 2^126 take the division.
+VKR_DI float rcp_ieee(float x)
+{
+#ifdef VKR_RCP_DIVIDE
+    return 1.0f / x;
+#endif
+    const float ax = __builtin_fabsf(x);
+    float r = __builtin_amdgcn_rcpf(x);
+    r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    if (__builtin_expect(!(ax >= 0x1p-126f && ax < 0x1p126f), 0)) r = 1.0f / x;
+    return r;
+}
+
 VKR_DI bool tri_hit(V3 ro, V3 rdir, float4 ta, float4 tb4, float4 tc, float tmin, float tbest, float* uo, float* vo,
                     float* to)
 {
     V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
     V3 pvec = cross3(rdir, e2);
     float det = dot3(e1, pvec);
-    float inv = 1.0f / det;
+    float inv = rcp_ieee(det);
     V3 tvec = ro - v0;
     float u = dot3(tvec, pvec) * inv;
     V3 qvec = cross3(tvec, e1);
