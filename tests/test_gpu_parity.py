@@ -375,3 +375,44 @@ def test_gbuffer_vertex_normals_scaled_and_mirrored_instances(torch_mod, oracle_
     depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
     assert np.array_equal(to_np_u16(gb.normal), normal)
     ctx.close()
+
+
+def test_self_hit_retry_stress_coincident_layers(torch_mod, oracle_mod):
+    """G-buffer of the plain scene, rays traced against 13 copies of it stacked 0.4 mm apart (the origin rebuilt from
+    R16F depth is off the surface by more than that): a large share of first hits land within 1.5 x tMin of the ray
+    origin, so the traceRayVisibility self-hit retry
+    (rtao_trace_half.comp:186-193) runs for many rays.  K1 does that retry in place while other rays of the item are
+    still in flight; the result must stay bit-identical to the oracle's sequential two-query form."""
+    import dataclasses
+    from vulkanrenderer_amd import make_test_scene, camera_path
+    from vulkanrenderer_amd.renderer import PassExecuteContext, trace_stats, trace_stats_enable
+    from oracle import oracle as O_
+    base = make_test_scene()
+    xf = base.instance_transform
+    layers = []
+    for k in range(-6, 7):
+        c = xf.copy()
+        c[:, 3] += k * 4e-4; c[:, 7] += k * 4e-4; c[:, 11] += k * 4e-4
+        layers.append(c)
+    scene = dataclasses.replace(base, instance_mesh=np.concatenate([base.instance_mesh] * len(layers)),
+                                instance_transform=np.concatenate(layers), name="coincident")
+    gb_scene = O_.OracleScene(base)
+    W, H, rays = 192, 108, 8
+    O, osc, ctx, rt, gb, rpass, opass, fs = _setup(scene, W, H, rays, 2, torch_mod)
+    for frame, (eye, tgt) in enumerate(camera_path(base, 3)):
+        ubo = fs.update(eye, tgt)
+        depth, normal, wp, ng, valid = gb_scene.gbuffer(ubo, W, H)
+        gb.upload(depth, normal, wp, ng, valid)
+        trace_stats_enable(ctx, frame == 0)       # frame 0 through the counting build of K1, the rest through the product one
+        trace_stats(ctx, reset=True)
+        rpass.execute(PassExecuteContext(ubo=ubo))
+        ctx.sync()
+        if frame == 0:
+            st = trace_stats(ctx, reset=True)
+            nvalid = int(np.asarray(valid).astype(bool).sum())
+            retries = st.rays - rays * nvalid
+            print(f"coincident: {nvalid} px, {st.rays} queries, {retries} retries ({retries / max(1, rays * nvalid):.1%})")
+            assert retries >= rays * nvalid // 10, "the scene is meant to make the retry common"
+        ref_full, ref_mask = opass.execute(ubo, depth, normal, want_mask=True)
+        _check_frame(f"coincident frame {frame}", ctx, rpass, opass, ref_full, ref_mask)
+    ctx.close()
