@@ -942,6 +942,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const uint32_t n = lq < 64u ? lq : 64u;
                     lq -= n;
                     const bool act = (uint32_t)lane < n;
+                    VKR_PRIO_HI
                     const uint32_t it = act ? s_lq[VKR_BOUND(lq + (uint32_t)lane, K1_LQ, 1024)] : 0u;      // item 0: ray 0, triangle 0 (valid addresses)
                     const uint32_t ray = VKR_BOUND(it >> SH, RAYS, 2048), pl = VKR_BOUND(it & PMASK, 2u * sc.tri_count, 4096);
                     const uint32_t cntT = act ? (pl & 1u) + 1u : 0u;
@@ -960,6 +961,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                         const float4* tq = tp + ((cntT > 1u) ? 3 : 0);
                         ta1 = tq[0]; tb1 = tq[1]; tc1 = tq[2];
                     }
+                    VKR_PRIO_LO
                     const V3 ro = V3{a.x, a.y, a.z}, rdir = V3{d.x, d.y, d.z};
                     const float tmin = a.w;
                     float tbest = tbest0;
@@ -993,6 +995,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
 #else
                     const bool same_record = true;
 #endif
+                    VKR_PRIO_HI
                     if (tbest < tbest0 && same_record) atomicMin((uint32_t*)&s_rb[ray].w, f2u(tbest));   // t > tmin >= 0: bits order like floats
 #if K1_EARLY_RETRY
                     retry_now(tbest < tbest0 && tbest <= tmin * 1.5f && same_record, ray); // :193
@@ -1070,6 +1073,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     // one lane-major prefix sum instead of per-slot ballots makes a ray's siblings pop together and costs 9 %)
                     const uint32_t rayhi = in.rayhi, rayhi_leaf = in.rayhi + 0x80000000u;   // + leaf reference: bit 31 cancels
                     const bool l0 = (int)r0 < 0, l1 = (int)r1 < 0, l2 = (int)r2 < 0, l3 = (int)r3 < 0;
+                    VKR_PRIO_HI
                     const unsigned long long hm0 = __ballot(h0), hm1 = __ballot(h1), hm2 = __ballot(h2), hm3 = __ballot(h3);
                     const unsigned long long lm0 = __ballot(l0), lm1 = __ballot(l1), lm2 = __ballot(l2), lm3 = __ballot(l3);
                     const unsigned long long mn0 = hm0 & ~lm0, mn1 = hm1 & ~lm1, mn2 = hm2 & ~lm2, mn3 = hm3 & ~lm3;
@@ -1125,8 +1129,10 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     }
                 };
                 const bool act0 = (uint32_t)lane < n, act1 = (uint32_t)lane + 64u < n;
+                VKR_PRIO_HI
                 const uint32_t it0 = act0 ? s_nq[VKR_BOUND(nq + (uint32_t)lane, K1_NQ, 65536)] : 0u;
                 const NodeIn in0 = fetch(it0);
+                VKR_PRIO_LO
                 if (K1_STEP > 64u && n > 64u) {                                     // wave-uniform
                     const uint32_t it1 = act1 ? s_nq[nq + 64u + (uint32_t)lane] : 0u;
                     const NodeIn in1 = fetch(it1);
@@ -1169,6 +1175,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
             }
         }
         VKR_STAMP(5)
+        VKR_PRIO_LO
 
         // ------------------------------------------------------------------ phase 3: per pixel resolve + temporal
         if (owner) {

@@ -696,6 +696,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
 #ifdef VKR_SUN_STATS
                 if (lane == 0) st_wtri++;
 #endif
+                VKR_PRIO_HI
                 if ((uint32_t)lane < n) {
                     const uint32_t tri = s_tq[tq + (uint32_t)lane];
                     const uint32_t pix = (uint32_t)s_tqp[tq + (uint32_t)lane];
@@ -707,6 +708,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                         const V3 ro = V3{s_ox[pix], s_oy[pix], s_oz[pix]};
                         const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
                         const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
+                        VKR_PRIO_LO
                         const V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
                         // tri_hit() with its direction-independent terms hoisted: same operations, same bits per ray
                         const V3 tvec = ro - v0;
@@ -725,6 +727,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                                              (t > tmin && t < tmax);
                             got |= hit ? (1u << k) : 0u;
                         }
+                        VKR_PRIO_HI
                         if (got & ~have) atomicOr(&s_mask[pix], got);
                     }
                 }
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                 lq -= n;
                 uint32_t cntT = 0, first = 0, pix = 0;
                 V3 ro = v3(0, 0, 0);
+                VKR_PRIO_HI
                 if ((uint32_t)lane < n) {
                     const uint32_t ref = s_lq[lq + (uint32_t)lane];
                     pix = (uint32_t)s_lqp[lq + (uint32_t)lane];
@@ -756,6 +760,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
 #endif
                         const float4* tp = (const float4*)(tri_base + (size_t)(first + j) * 48u);
                         const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
+                        VKR_PRIO_LO
                         const V3 v0 = V3{ta.x, ta.y, ta.z}, e1 = V3{tb4.x, tb4.y, tb4.z}, e2 = V3{tc.x, tc.y, tc.z};
                         const V3 g = (e1 + e2) * (1.0f / 3.0f);                      // centroid - v0
                         const V3 a1 = e1 - g, a2 = e2 - g;
@@ -769,6 +774,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
                                           (__builtin_fabsf(h) + __builtin_fabsf(wp.x) + __builtin_fabsf(wp.y) + __builtin_fabsf(wp.z)) * 1e-5f + 1e-7f;
                         keep = !(perp2 > lim * lim);                                 // NaN keeps
                     }
+                    VKR_PRIO_HI
                     const unsigned long long km = __ballot(keep);
                     if (keep) { const uint32_t ix = tq + mbcnt64(km); s_tq[ix] = first + j; s_tqp[ix] = (uint8_t)pix; }
                     tq += (uint32_t)__popcll(km);
@@ -787,6 +793,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
             // one basic block (see k_trace_q): lanes without an item, or whose pixel is already fully occluded, run on
             // their (or item 0's) addresses with an exit distance that fails every test
             const bool act = (uint32_t)lane < n;
+            VKR_PRIO_HI
             const uint32_t item = act ? s_nq[nq + (uint32_t)lane] : 0u;
             const uint32_t pix = item >> KQ_NODE_BITS;
             const bool live = act && (s_mask[pix] & full) != full;
@@ -798,6 +805,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
             const float4* np = (const float4*)(node_base + ((size_t)node << 6));
             const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             const V3 o = V3{s_ox[pix], s_oy[pix], s_oz[pix]};
+            VKR_PRIO_LO
             const float sx = q2.z, sy = q2.w, sz = q0.w;
             // plane - origin per axis: fma(q, s, node origin - ray origin)
             const float bx = q0.x - o.x, by = q0.y - o.y, bz = q0.z - o.z;
@@ -840,9 +848,11 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
         }                                                                                                           \
         nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
     }
+            VKR_PRIO_HI
             VKR_APPEND(h0, r0) VKR_APPEND(h1, r1) VKR_APPEND(h2, r2) VKR_APPEND(h3, r3)
 #undef VKR_APPEND
         }
+        VKR_PRIO_LO
 
         // ------------------------------------------------------------------ phase 3: per pixel
         for (int j = 0; j < (int)(pix_per_chunk / 64u); ++j) {

@@ -122,6 +122,21 @@ struct NodeDec {
     uint32_t ref[4];
 };
 
+// Wave priority in the queue kernels (k_trace_q, k_shadow_sun_pkt, k_shadow_q): raised (s_setprio) while a step pops its
+// items and issues their loads, and again from the end of its arithmetic through its appends; 0 during the slab / triangle
+// arithmetic and the per-pixel phases.  A wave that is about to put loads in flight goes ahead of waves that only compute,
+// so the CU keeps more of them in flight: -2.6 % on K1 (C3).  -DVKR_WAVE_PRIO=0 turns it off.
+#ifndef VKR_WAVE_PRIO
+#define VKR_WAVE_PRIO 1
+#endif
+#if VKR_WAVE_PRIO
+#define VKR_PRIO_HI __builtin_amdgcn_s_setprio(VKR_WAVE_PRIO);
+#define VKR_PRIO_LO __builtin_amdgcn_s_setprio(0);
+#else
+#define VKR_PRIO_HI
+#define VKR_PRIO_LO
+#endif
+
 VKR_DI float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
 
 VKR_DI void decode_node(const float4* np, NodeDec& n)
