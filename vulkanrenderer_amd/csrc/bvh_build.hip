@@ -362,6 +362,28 @@ __global__ __launch_bounds__(256) void k_emit_sorted(BuildIn in, const uint32_t*
     }
 }
 
+// Alpha records: for every MASK triangle (class 2) of the final order its three UVs, its material's cutoff and alpha-texture
+// descriptor, 48 bytes beside the triangle, so that the alpha test of a candidate (rtao_trace_half.comp:163-173) loads them
+// together with the triangle instead of walking lut -> indices -> uvs and lut -> material tables.  Same values, same
+// arithmetic afterwards (traverse.hpp alpha_test_rec).
+__global__ __launch_bounds__(256) void k_alpha_records(const float4* tris, uint32_t n, const uint2* lut, const uint32_t* indices,
+                                                       const float2* uvs, const float4* material_params, const AlphaTexDev* alpha_tex,
+                                                       float4* rec)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t mw = f2u(tris[(size_t)i * 3].w);
+    if ((mw >> 28) != 2u) return;
+    const uint32_t prim = f2u(tris[(size_t)i * 3 + 1].w);
+    const uint2 l = lut[mw & 0x0fffffffu];
+    const uint32_t i0 = indices[l.y + prim * 3u + 0u], i1 = indices[l.y + prim * 3u + 1u], i2 = indices[l.y + prim * 3u + 2u];
+    const float2 a = uvs[i0], b = uvs[i1], c = uvs[i2];
+    const AlphaTexDev t = alpha_tex[l.x];
+    rec[(size_t)i * 3] = make_float4(a.x, a.y, b.x, b.y);
+    rec[(size_t)i * 3 + 1] = make_float4(c.x, c.y, material_params[l.x].x, 0.0f);
+    rec[(size_t)i * 3 + 2] = make_float4(u2f(t.offset), u2f(t.w), u2f(t.h), u2f(l.x));
+}
+
 #ifndef VKR_TL_MAX
 #define VKR_TL_MAX 1024
 #endif
@@ -1442,6 +1464,9 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
         k_treelet_ploc<<<blocks, TL_MAX, 0, st>>>(c->d_treelet.p, c->d_bin_child.p, c->d_bin_range.p, c->d_leaf_parent.p,
                                                c->d_node_parent.p, c->d_tris.p, c->d_perm.p);
     }
+    if (!refit_only)   // the triangle order is final here; a refit keeps it
+        k_alpha_records<<<nb, 256, 0, st>>>(c->d_tris.p, n, c->d_lut.p, c->d_indices.p, c->d_uvs.p, c->d_material_params.p,
+                                              c->d_alpha_tex.p, c->d_tri_alpha.p);
     if (!refit_only && c->validate_tree) VKR_TRY(validate_binary_tree(c, st));
     if (n == 1) {
         k_single<<<1, 64, 0, st>>>(c->d_tris.p, c->d_nodes.p, c->d_wide_bref.p, c->d_height.p, (WideCtl*)c->d_wide_ctl.p,

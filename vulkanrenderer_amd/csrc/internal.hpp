@@ -139,6 +139,7 @@ struct vkr_ctx {
     vkr::DevBuf<float4> d_node_box;          // 2 x float4 per binary node: min.xyz|height, max.xyz
     vkr::DevBuf<uint32_t> d_wide_ctl, d_wide_bin;
     vkr::DevBuf<float4> d_tris;              // 3 x float4 per leaf, Morton order
+    vkr::DevBuf<float4> d_tri_alpha;         // 3 x float4 per triangle (MASK ones written): UVs, cutoff and texture descriptor for the alpha test
     vkr::DevBuf<uint32_t> d_perm;            // sorted position -> flat triangle id
     vkr::DevBuf<uint32_t> d_leaf_parent, d_node_parent, d_flags;
     vkr::DevBuf<uint64_t> d_keys[2];
@@ -195,6 +196,7 @@ inline SceneDev scene_dev(const vkr_ctx* c)
     s.material_params = c->d_material_params.p;
     s.alpha_tex = c->d_alpha_tex.p;
     s.alpha_data = c->d_alpha_data.p;
+    s.tri_alpha = c->d_tri_alpha.p;
     s.normals = c->d_normals.p;
     s.mesh_has_normals = c->d_mesh_has_normals.p;
     s.inst_first_tri = c->d_inst_first_tri.p;

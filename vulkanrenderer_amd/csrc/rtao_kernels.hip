@@ -867,6 +867,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
             auto alpha_step = [&](uint32_t n, uint32_t base) {
                 bool trig = false;
                 uint32_t tray = 0;
+                VKR_PRIO_HI          // a chain of dependent loads (triangle + alpha record, texture table, texels) with little arithmetic between them
                 if ((uint32_t)lane < n) {
                     const uint32_t it = s_aq[VKR_BOUND(base + (uint32_t)lane, K1_AQ, 2)];
                     const uint32_t tri = VKR_BOUND(it & PMASK, sc.tri_count, 4), ray = VKR_BOUND(it >> SH, RAYS, 8);
@@ -874,10 +875,12 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                     const V3 d = ray_dir(ray);
                     const float4* tp = (const float4*)(tri_base + (size_t)tri * 48u);
                     const float4 ta = tp[0], tb4 = tp[1], tc = tp[2];
+                    const float4* ar = sc.tri_alpha + (size_t)tri * 3u;     // UVs, cutoff, texture descriptor: in flight with the triangle
+                    const float4 ar0 = ar[0], ar1 = ar[1], ar2 = ar[2];
                     float u, v, t;
                     const float tbest = s_rb[ray].w;
                     if (tri_hit(V3{a.x, a.y, a.z}, V3{d.x, d.y, d.z}, ta, tb4, tc, a.w, tbest, &u, &v, &t) &&
-                        alpha_test(sc, f2u(ta.w) & 0x0fffffffu, f2u(tb4.w), u, v)) {
+                        alpha_test_rec(sc, ar0, ar1, ar2, u, v)) {
                         atomicMin((uint32_t*)&s_rb[ray].w, f2u(t));
                         trig = t <= a.w * 1.5f;                                     // :193
                         tray = ray;

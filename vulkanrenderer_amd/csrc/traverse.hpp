@@ -64,6 +64,7 @@ struct SceneDev {
     const float4* material_params;
     const AlphaTexDev* alpha_tex;
     const uint8_t* alpha_data;
+    const float4* tri_alpha;    // 3 x float4 per triangle, same order as tris: {uv0, uv1}, {uv2, cutoff, -}, {texture offset, w, h, -}; written for MASK triangles only
     // G-buffer producer (depth_prepass.vert:47-48): vertex normals and the instance a triangle came from
     const float* normals;            // merged xyz
     const uint32_t* mesh_has_normals;
@@ -79,9 +80,8 @@ enum { Q_AO = 0, Q_SHADOW = 1, Q_PRIMARY = 2, Q_PRIMARY_MS = 3 };
 struct TraceCounters { uint32_t nodes, tris, wave_node_iters, wave_tri_iters; };
 
 // baseColor alpha: LOD 0, bilinear, REPEAT (rtao_trace_half.comp:170)
-VKR_DI float sample_alpha(const SceneDev& sc, uint32_t mat, V2 uv)
+VKR_DI float sample_alpha_tex(const SceneDev& sc, AlphaTexDev t, V2 uv)
 {
-    AlphaTexDev t = sc.alpha_tex[mat];
     if (t.w == 0 || t.h == 0) return 1.0f;
     float x = uv.x * (float)t.w - 0.5f;
     float y = uv.y * (float)t.h - 0.5f;
@@ -102,6 +102,8 @@ VKR_DI float sample_alpha(const SceneDev& sc, uint32_t mat, V2 uv)
     return top + ay * (bot - top);
 }
 
+VKR_DI float sample_alpha(const SceneDev& sc, uint32_t mat, V2 uv) { return sample_alpha_tex(sc, sc.alpha_tex[mat], uv); }
+
 // MASK candidate: barycentric UV -> alpha >= cutoff (rtao_trace_half.comp:163-173)
 VKR_DI bool alpha_test(const SceneDev& sc, uint32_t mesh, uint32_t prim, float bu, float bv)
 {
@@ -114,6 +116,16 @@ VKR_DI bool alpha_test(const SceneDev& sc, uint32_t mesh, uint32_t prim, float b
     float2 a = sc.uvs[i0], b = sc.uvs[i1], c = sc.uvs[i2];
     V2 uv = V2{(a.x * w0 + b.x * bu) + c.x * bv, (a.y * w0 + b.y * bu) + c.y * bv};
     return sample_alpha(sc, lut.x, uv) >= cutoff;
+}
+
+// The same test from the triangle's alpha record (bvh_build.hip k_alpha_records): the three UVs, the material's cutoff and
+// its texture descriptor sit next to the triangle instead of behind lut -> indices -> uvs and lut -> material tables, so the
+// chain of dependent loads is {triangle, record} -> texels.  The tables only change in vkr_scene_upload, which a build follows.
+VKR_DI bool alpha_test_rec(const SceneDev& sc, float4 r0, float4 r1, float4 r2, float bu, float bv)
+{
+    float w0 = (1.0f - bu) - bv;
+    V2 uv = V2{(r0.x * w0 + r0.z * bu) + r1.x * bv, (r0.y * w0 + r0.w * bu) + r1.y * bv};
+    return sample_alpha_tex(sc, AlphaTexDev{f2u(r2.x), f2u(r2.y), f2u(r2.z), 0u}, uv) >= r1.z;
 }
 
 // One decoded wide node: 24 planes + 4 child refs.

@@ -160,7 +160,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_positions.release(); c->d_indices.release(); c->d_uvs.release(); c->d_lut.release();
     c->d_mesh_class.release(); c->d_material_params.release(); c->d_alpha_tex.release(); c->d_alpha_data.release();
     c->d_inst_mesh.release(); c->d_inst_first_tri.release(); c->d_inst_xf.release();
-    c->d_nodes.release(); c->d_tris.release(); c->d_perm.release(); c->d_leaf_parent.release();
+    c->d_nodes.release(); c->d_tris.release(); c->d_tri_alpha.release(); c->d_perm.release(); c->d_leaf_parent.release();
     c->d_node_parent.release(); c->d_flags.release();
     c->d_bin_child.release(); c->d_bin_range.release(); c->d_deposit.release(); c->d_node_box.release();
     c->d_wide_ctl.release(); c->d_wide_bin.release(); c->d_wide_bref.release();
@@ -324,6 +324,7 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     HIP_OR_FAIL(c, c->d_wide_ctl.alloc(4 + 72));
     HIP_OR_FAIL(c, c->d_wide_bin.alloc(n));
     HIP_OR_FAIL(c, c->d_tris.alloc(n * 3));
+    HIP_OR_FAIL(c, c->d_tri_alpha.alloc(n * 3));
     HIP_OR_FAIL(c, c->d_perm.alloc(n));
     HIP_OR_FAIL(c, c->d_leaf_parent.alloc(n));
     HIP_OR_FAIL(c, c->d_node_parent.alloc(n));
