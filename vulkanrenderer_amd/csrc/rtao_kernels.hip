@@ -737,6 +737,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
         uint32_t item = 0;
         const uint32_t c0 = slab * tiles_x / (uint32_t)K1_SLABS, c1 = (slab + 1u) * tiles_x / (uint32_t)K1_SLABS;
         const uint32_t slab_items = (c1 - c0) * item_rows;
+        VKR_PRIO_HI      // the counter's round trip and the pixel records' loads come next
         if (lane == 0) item = atomicAdd(tile_counter + slab * 16u, 1u);
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         if (item >= slab_items) {                               // this slab is drained (every wave gets here: counters only grow)
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
 #else
         if (px < W && py < y1) setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);   // :233-235
 #endif
+        VKR_PRIO_LO      // ray generation is arithmetic
         VKR_STAMP(8)
         const bool valid = pc.valid;
         const float radius = pc.radius, viewZ = pc.viewZ;     // kept across the queue loop (K1_SPLIT: the radius only)
@@ -1178,7 +1180,6 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
             }
         }
         VKR_STAMP(5)
-        VKR_PRIO_LO
 
         // ------------------------------------------------------------------ phase 3: per pixel resolve + temporal
         if (owner) {

@@ -135,9 +135,10 @@ struct NodeDec {
 };
 
 // Wave priority in the queue kernels (k_trace_q, k_shadow_sun_pkt, k_shadow_q): raised (s_setprio) while a step pops its
-// items and issues their loads, and again from the end of its arithmetic through its appends; 0 during the slab / triangle
-// arithmetic and the per-pixel phases.  A wave that is about to put loads in flight goes ahead of waves that only compute,
-// so the CU keeps more of them in flight: -2.6 % on K1 (C3).  -DVKR_WAVE_PRIO=0 turns it off.
+// items and issues their loads, and again from the end of its arithmetic through its appends (K1: also through the alpha
+// steps, the visibility sums, the work-counter round trip and the pixel-record loads); 0 during the slab / triangle
+// arithmetic and ray generation.  A wave that is about to put loads in flight goes ahead of waves that only compute, so the
+// CU keeps more of them in flight: -3 % on K1 (C3).  -DVKR_WAVE_PRIO=0 turns it off.
 #ifndef VKR_WAVE_PRIO
 #define VKR_WAVE_PRIO 1
 #endif
