@@ -12,6 +12,7 @@ names=()
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
   names+=($name)
+  [ -n "$SKIP_BUILD" ] && continue
   ( bd=/tmp/vkr_variant_$name; mkdir -p $bd
     for f in vkr_api bvh_build rtao_kernels shadow_kernels indirect_build ibl_kernels comm; do
       /opt/rocm/bin/hipcc $BASE $flags -I$SRC -c $SRC/$f.hip -o $bd/$f.o &

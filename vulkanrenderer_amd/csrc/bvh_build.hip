@@ -1095,6 +1095,9 @@ VKR_DI void quantise_wide(float4* node, const float lo[4][3], const float hi[4][
     node[2] = make_float4(u2f(q[4]), u2f(q[5]), scale[0], scale[1]);
 }
 
+#ifndef VKR_WIDE_SLOT_ORDER
+#define VKR_WIDE_SLOT_ORDER 1   // 1: child slots in Morton order; 0: the expanded child's halves at its slot and at the end
+#endif
 __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bin_child, const uint2* bin_range,
                                                     const float4* node_box, const float4* tris, float4* nodes,
                                                     uint4* wide_bref, uint32_t* wide_bin, const BvhBounds* bnd)
@@ -1136,10 +1139,15 @@ __global__ __launch_bounds__(256) void k_wide_level(WideCtl* ctl, const int2* bi
             }
             if (pick < 0) break;
             int2 c = bin_child[cand[pick]];
+#if VKR_WIDE_SLOT_ORDER
             for (int k = ncand; k > pick + 1; --k) cand[k] = cand[k - 1];     // keep the slots in Morton (left to right) order
             cand[pick] = c.x;
             cand[pick + 1] = c.y;
             ++ncand;
+#else
+            cand[pick] = c.x;                                                 // round-1 order: the split child's right half goes last
+            cand[ncand++] = c.y;
+#endif
         }
     }
     uint32_t nint = 0;

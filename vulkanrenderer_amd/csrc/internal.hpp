@@ -165,6 +165,11 @@ struct vkr_ctx {
     int num_cus = 0;
     vkr::DevBuf<float4> d_pixctx;            // K1_SPLIT: 3 float4 per pixel from k_pix_setup (rtao_kernels.hip)
     vkr::DevBuf<float2> d_vis;               // K1_SPLIT: summed visibility + hit bits per pixel, k_trace_q -> k_pix_resolve
+    vkr::DevBuf<float4> d_tile_bounds;       // K1_CUT: per 8x8 tile of a launch, the bound of its ray segments (k_pix_setup -> k_tile_cut)
+    vkr::DevBuf<uint4> d_cuts;               // K1_CUT: per 8x8 tile of a launch, header + entries of its entry cut (k_tile_cut)
+    uint32_t cut_l2_begin = 0, cut_l2_count = 0;   // third level of the wide tree, when k_tile_cut may start there (vkr_bvh_build)
+    uint32_t cut_max = 16;                   // entries per cut at most (VKR_CUT_MAX, <= K1_CUT_MAX)
+    float cut_small = 1.0f;                  // a node joins the cut once its half area is <= this x the half area of the tile's ray bound (VKR_CUT_SMALL)
     vkr::DevBuf<float4> d_nz;                // per-frame decoded normal.xyz + clamped depth (A-Trous operand)
     uint32_t frame_parity = 0;               // FrameManager currentFrame % 2
     uint32_t last_curr = 0;

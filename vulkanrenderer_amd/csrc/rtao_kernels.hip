@@ -331,7 +331,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 
     // ------------------------------------------------------------------ phase 2: per ray, dynamic pull
     {
-        const uint32_t total = nvalid * (uint32_t)rayCount;
+        const uint32_t total = (sc.tri_count != 0u) ? nvalid * (uint32_t)rayCount : 0u;   // an empty scene has a root, but nothing walks it
         uint32_t next = 0;                 // wave-uniform
         bool active = false, found = false, retried = false;
         uint32_t spill[2 * (VKR_MAX_STACK - VKR_LDS_STACK)];   // scratch: touched only by rays deeper than the LDS part
@@ -585,6 +585,16 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #ifndef K1_LQ
 #define K1_LQ 128          // leaf queue entries in LDS (>= 64; a node step's leaf pushes beyond it go to the global stack)
 #endif
+#ifndef K1_SLOT0_FIRST
+#define K1_SLOT0_FIRST 1  // node-step appends in reverse slot order, see the fast path of the node step
+#endif
+#ifndef K1_CUT
+#define K1_CUT 1           // 1: rays enter the tree at a per-tile cut (k_tile_cut) instead of at the root, see below
+#endif
+#ifndef K1_CUT_MAX
+#define K1_CUT_MAX 16      // entries of a tile's cut at most (16 B each in LDS, after a 16-byte header)
+#endif
+static_assert(K1_CUT_MAX >= 1 && K1_CUT_MAX <= 16, "k_tile_cut expands every open node of a round on 4 lanes each");
 constexpr uint32_t K1_GNQ = 4096;      // node-item overflow stack per wave (global)
 constexpr uint32_t K1_GLQ = 512;       // leaf-item overflow per wave (global): one node step pushes <= 4 * 128
 constexpr uint32_t K1_AQ = 128;        // alpha-test queue (LDS): drained whenever it holds a full wave of candidates (draining at one
@@ -605,7 +615,8 @@ __host__ __device__ inline QSliceLayout q_slice_layout(int rb)
 }
 __host__ __device__ inline size_t q_lds_bytes(int rb)
 {
-    return (size_t)(1u << rb) * (K1_DIR_LDS ? 44u : 32u) + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u + 32u + 16u;   // + retry bits + the trash word
+    return (size_t)(1u << rb) * (K1_DIR_LDS ? 44u : 32u) + (size_t)K1_NQ * 4u + (size_t)K1_LQ * 4u + (size_t)K1_AQ * 4u + 32u + 16u   // + retry bits + the trash word
+           + (K1_CUT ? (size_t)(K1_CUT_MAX + 1 + 3) * 16u : 0u);                                                                              // + the tile's cut
 }
 // pixels per work item: the largest power of two <= 64 with P * rayCount <= 2^RB
 __host__ __device__ inline int q_item_pixels(int rb, int rayCount)
@@ -638,22 +649,73 @@ VKR_DI float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v
 //   [0] worldPos.xyz | viewZ if the pixel casts rays, else 0      [1] geomNormal.xyz | radius      [2] bias, footprint, cos, sin
 // Rows: the launch's stripes, row j of the launch = image row y0 + (j / 8) * 8 * stripeMul + j % 8 (k_trace_q's tiles).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pix_setup(FrameParams fp, const uint16_t* depthP, uint16_t* histCurr, uint32_t* hitMask,
-                                                   int y0, int y1, int rows, float4* pixctx)
+// K1_CUT: the block is 64 pixels x the 8 rows of one stripe = eight 8x8 tiles, and it also leaves the bound of every tile's ray
+// segments for k_tile_cut (2 float4 per tile: minimum corner | valid flag, maximum corner): per pixel the half ball of radius
+// `radius + largest origin offset` around the offset origin (:375,418-430), reduced over the tile.
+VKR_DI float group8_min(float v)
 {
+    v = gmin(v, __shfl_xor(v, 1, 64)); v = gmin(v, __shfl_xor(v, 2, 64)); return gmin(v, __shfl_xor(v, 4, 64));
+}
+VKR_DI float group8_max(float v)
+{
+    v = gmax(v, __shfl_xor(v, 1, 64)); v = gmax(v, __shfl_xor(v, 2, 64)); return gmax(v, __shfl_xor(v, 4, 64));
+}
+constexpr int PIX_ROWS = K1_CUT ? 8 : 4;       // rows of a k_pix_setup / k_pix_resolve block
+
+__global__ __launch_bounds__(64 * PIX_ROWS) void k_pix_setup(FrameParams fp, const uint16_t* depthP, uint16_t* histCurr, uint32_t* hitMask,
+                                                   int y0, int y1, int rows, float4* pixctx, float4* tile_bounds, uint32_t tiles_x)
+{
+#if K1_CUT
+    __shared__ float s_b[8][8][6];            // [tile of the block][row][lo xyz, hi xyz]
+#endif
     const int px = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63u);
-    const int j = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    const int j = (int)blockIdx.y * PIX_ROWS + (int)(threadIdx.x >> 6);
     const int py = y0 + (j >> 3) * 8 * fp.stripeMul + (j & 7);
-    if (px >= fp.W || j >= rows || py >= y1) return;
-    const Img16 depth{depthP, fp.W, fp.H};
+    const bool inside = !(px >= fp.W || j >= rows || py >= y1);
     PixelCtx pc;
-    setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);
-    float4* o = pixctx + 3u * ((size_t)py * fp.W + px);
-    o[0] = make_float4(pc.worldPos.x, pc.worldPos.y, pc.worldPos.z, pc.valid ? pc.viewZ : 0.0f);
-    if (pc.valid) {
-        o[1] = make_float4(pc.geomNormal.x, pc.geomNormal.y, pc.geomNormal.z, pc.radius);
-        o[2] = make_float4(pc.bias, pc.footprint, pc.cs, pc.sn);
+    pc.valid = false;
+    if (inside) {
+        const Img16 depth{depthP, fp.W, fp.H};
+        setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);
+        float4* o = pixctx + 3u * ((size_t)py * fp.W + px);
+        o[0] = make_float4(pc.worldPos.x, pc.worldPos.y, pc.worldPos.z, pc.valid ? pc.viewZ : 0.0f);
+        if (pc.valid) {
+            o[1] = make_float4(pc.geomNormal.x, pc.geomNormal.y, pc.geomNormal.z, pc.radius);
+            o[2] = make_float4(pc.bias, pc.footprint, pc.cs, pc.sn);
+        }
     }
+#if K1_CUT
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (pc.valid) {
+        // a ray runs from o + d * dirOffset to o + d * (dirOffset + radius) with dirOffset <= slope * 1.65 (:421-423,430) and
+        // dot(n, d) >= 0 (:408-412; -0.01 allowed for rounding): inside the half ball of radius R around the offset origin o
+        const float slope = gmax(pc.bias * 0.5f, pc.footprint * 0.02f);
+        const float R = (pc.radius + slope * 1.65f) * 1.0001f + 1.0e-5f;
+        const float oc[3] = {pc.origin.x, pc.origin.y, pc.origin.z}, nc[3] = {pc.geomNormal.x, pc.geomNormal.y, pc.geomNormal.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float side = gmin(1.0f, sqrt_(gmax(1.0f - nc[a] * nc[a], 0.0f)) + 0.02f);   // extent against the normal
+            const float pad = 1.0e-4f + __builtin_fabsf(oc[a]) * 1.0e-6f;
+            lo[a] = oc[a] - R * (nc[a] > 0.0f ? side : 1.0f) - pad;
+            hi[a] = oc[a] + R * (nc[a] < 0.0f ? side : 1.0f) + pad;
+        }
+    }
+    const int t8 = (int)(threadIdx.x & 63u) >> 3, r8 = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = group8_min(lo[a]), h = group8_max(hi[a]);
+        if ((threadIdx.x & 7u) == 0u) { s_b[t8][r8][a] = l; s_b[t8][r8][3 + a] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 48u) {
+        const int t = (int)threadIdx.x / 6, a = (int)threadIdx.x % 6;
+        float v = s_b[t][0][a];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v = (a < 3) ? gmin(v, s_b[t][r][a]) : gmax(v, s_b[t][r][a]);
+        const uint32_t tile_x = blockIdx.x * 8u + (uint32_t)t;
+        if (tile_x < tiles_x) ((float*)(tile_bounds + 2u * ((size_t)blockIdx.y * tiles_x + tile_x)))[a < 3 ? a : a + 1] = v;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_pix_resolve(FrameParams fp, const uint16_t* depthP, const uint16_t* histPrevP, uint16_t* histCurr,
@@ -673,13 +735,100 @@ __global__ __launch_bounds__(256) void k_pix_resolve(FrameParams fp, const uint1
     resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc, v.x, f2u(v.y));
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1_CUT: the entry cut of an 8x8 tile.  AO rays are short (tMax = radius <= 1.92 m, :371-372,430) and the pixels of a tile
+// are centimetres apart, so all rays of a tile live in one small box -- and every one of them would walk the same upper
+// levels of the tree to get there (about a third of its node visits).  k_tile_cut walks them ONCE per tile: one wave per
+// tile bounds the tile's ray segments (per pixel: the hemisphere of radius `radius + largest origin offset` around the
+// offset origin, :375,418-430), then descends from the root through every child whose box overlaps that bound, level by
+// level (up to 16 open nodes x 4 children on the 64 lanes), until the nodes are no larger than the bound (`small_factor`),
+// are leaves, or the cut would exceed `cut_max` entries (then the nodes still open join the cut as they are).  A cut entry is
+// 16 bytes: the child's box clipped to the bound, as six fp16 offsets from the bound's minimum corner (widened outward by
+// more than the fp16 rounding), and the child reference.  k_trace_q tests every ray of an item against the tile's entries
+// (uniform LDS reads, two rays per lane) and queues it at the entries it overlaps, instead of queueing it at the root.
+// Box tests are conservative, so the closest committed hit of every ray -- and with it every output bit -- is unchanged.
+// Record per tile: [0] bound minimum xyz | number of entries, [1 ..] entries.
+// ---------------------------------------------------------------------------------------------
+VKR_DI uint32_t pack_h2(float a, float b)
+{
+    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
+}
+VKR_DI float h_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+VKR_DI float h_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+
+__global__ __launch_bounds__(64) void k_tile_cut(SceneDev sc, uint32_t n_tiles, const float4* tile_bounds, uint4* cuts, uint32_t cut_max,
+                                                 float small_factor, uint32_t l2_begin, uint32_t l2_count)
+{
+    __shared__ uint4 s_open[16];
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    uint4* out = cuts + (size_t)tile * (K1_CUT_MAX + 1);
+    const float4 b0 = tile_bounds[2u * (size_t)tile], b1 = tile_bounds[2u * (size_t)tile + 1u];   // k_pix_setup: bound of the tile's ray segments
+    const float amin[3] = {b0.x, b0.y, b0.z}, amax[3] = {b1.x, b1.y, b1.z};
+    uint32_t ncut = 0;
+    if (amin[0] <= amax[0] && sc.tri_count != 0u) {
+        const float ex = amax[0] - amin[0], ey = amax[1] - amin[1], ez = amax[2] - amin[2];
+        const float area_lim = small_factor * ((ex * ey + ey * ez) + ez * ex);
+        const float wx = ex * 0.002f + 1.0e-6f, wy = ey * 0.002f + 1.0e-6f, wz = ez * 0.002f + 1.0e-6f;   // > fp16 rounding of a value <= extent
+        if (lane == 0) s_open[0] = make_uint4(pack_h2(-wx, -wy), pack_h2(-wz, ex + wx), pack_h2(ey + wy, ez + wz), 0u);   // the root: everything
+        uint32_t nopen = 1;
+        // The first round opens the third level of the tree directly (its nodes are numbered l2_begin .. l2_begin + l2_count - 1 by the
+        // level-order numbering of k_wide_level; every tile would get there through the same two rounds): three dependent loads
+        // less per tile.  If that alone breaks the budget, the descent starts over at the root.
+        bool shortcut = l2_count >= 1u && l2_count <= 16u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        while (nopen != 0u) {
+            const uint32_t slot = (uint32_t)lane >> 2, k = (uint32_t)lane & 3u;
+            const bool act = slot < (shortcut ? l2_count : nopen);
+            const uint32_t node = act ? (shortcut ? l2_begin + slot : s_open[slot].w) : 0u;
+            const float4* np = sc.nodes + (size_t)node * 4u;
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            const uint32_t sh8 = 8u * k;
+            const uint32_t ref = k == 0u ? f2u(q3.x) : (k == 1u ? f2u(q3.y) : (k == 2u ? f2u(q3.z) : f2u(q3.w)));
+            // the child's box exactly as decode_node() sees it
+            const float mnx = fma_((float)((f2u(q1.x) >> sh8) & 0xffu), q2.z, q0.x), mxx = fma_((float)((f2u(q1.w) >> sh8) & 0xffu), q2.z, q0.x);
+            const float mny = fma_((float)((f2u(q1.y) >> sh8) & 0xffu), q2.w, q0.y), mxy = fma_((float)((f2u(q2.x) >> sh8) & 0xffu), q2.w, q0.y);
+            const float mnz = fma_((float)((f2u(q1.z) >> sh8) & 0xffu), q0.w, q0.z), mxz = fma_((float)((f2u(q2.y) >> sh8) & 0xffu), q0.w, q0.z);
+            const bool ov = act && ref != VKR_CHILD_NONE && mnx <= amax[0] && mxx >= amin[0] && mny <= amax[1] && mxy >= amin[1] &&
+                            mnz <= amax[2] && mxz >= amin[2];
+            const float dx = mxx - mnx, dy = mxy - mny, dz = mxz - mnz;
+            const bool closed = ov && ((int)ref < 0 || ((dx * dy + dy * dz) + dz * dx) <= area_lim);
+            const bool opened = ov && !closed;
+            const unsigned long long cm = __ballot(closed), om = __ballot(opened);
+            const uint32_t nc = (uint32_t)__popcll(cm), no = (uint32_t)__popcll(om);
+            if (ncut + nc + no > cut_max) {
+                if (shortcut) { shortcut = false; continue; }         // from the root after all (the root entry is in s_open[0])
+                break;                                                // the nodes still open join the cut as they are
+            }
+            shortcut = false;
+            // clipped to the bound, relative to its minimum corner, widened
+            const uint4 e = make_uint4(pack_h2(gmax(mnx, amin[0]) - amin[0] - wx, gmax(mny, amin[1]) - amin[1] - wy),
+                                       pack_h2(gmax(mnz, amin[2]) - amin[2] - wz, gmin(mxx, amax[0]) - amin[0] + wx),
+                                       pack_h2(gmin(mxy, amax[1]) - amin[1] + wy, gmin(mxz, amax[2]) - amin[2] + wz), ref);
+            if (closed) out[1u + ncut + mbcnt64(cm)] = e;
+            ncut += nc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every lane has read its open entry
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (opened) s_open[mbcnt64(om)] = e;
+            nopen = no;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if ((uint32_t)lane < nopen) out[1u + ncut + (uint32_t)lane] = s_open[lane];
+        ncut += nopen;
+    }
+    if (lane == 0) out[0] = make_uint4(f2u(amin[0]), f2u(amin[1]), f2u(amin[2]), ncut);
+}
+
 struct NodeIn { float4 a, b, q0, q1, q2, q3; uint32_t rayhi; };   // one popped node item with its operands in flight
 
 template <bool STATS, int RB>
 __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k_trace_q(
     SceneDev sc, FrameParams fp, const uint16_t* depthP, const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
     int y0, int y1, uint32_t tiles_x, uint32_t n_items, float4* rayBuf, uint32_t* tile_counter, unsigned long long* stats,
-    const float4* pixctx, float2* visOut)
+    const float4* pixctx, float2* visOut, const uint4* cuts)
 {
     constexpr uint32_t RAYS = 1u << RB;
     constexpr uint32_t SH = 32u - (uint32_t)RB;              // item = ray << SH | payload
@@ -697,6 +846,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     uint32_t* s_aq = s_lq + K1_LQ;                            // MASK candidates: ray << SH | triangle
     uint32_t* s_retry = s_aq + K1_AQ;                         // K1_EARLY_RETRY: one bit per ray, set when it was re-traced (8 words)
     (void)s_retry;
+    uint4* s_cut = (uint4*)(s_retry + 12);                    // K1_CUT: [0] bound minimum | entries, [1 ..] the tile's cut entries
+    (void)s_cut;
 
     const int rayCount = fp.rayCount;                         // :252
     const int lane = threadIdx.x;
@@ -711,7 +862,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     const char* node_base = (const char*)sc.nodes;
     const char* tri_base = (const char*)sc.tris;
     TraceCounters cnt{0, 0, 0, 0};
-    uint32_t nrays = 0, nspill = 0;
+    uint32_t nrays = 0, nspill = 0, ncuttest = 0, ncuthit = 0;
+    (void)ncuttest; (void)ncuthit;
     // pixels per item P (a power of two), G = 64 / P lanes per pixel: lane = g * P + p generates rays g, g + G, ...
     const int P = q_item_pixels(RB, rayCount), G = 64 / P;
     const int plane = lane & (P - 1), grp = lane / P;
@@ -757,6 +909,17 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
         PixelCtx pc;
         pc.valid = false;
         pc.radius = 0.0f; pc.viewZ = 0.0f; pc.worldPos = v3(0, 0, 0);
+#if K1_CUT
+        // the tile's cut (k_tile_cut): header + entries, one uint4 per lane, in flight with the pixel records
+        // Slots past the cut's last entry (what k_tile_cut did not write, and three more: the injection reads four entries per
+        // turn) hold a box 65 km off the bound's corner, which no ray of <= 2 m reaches.
+        if (lane <= K1_CUT_MAX + 3) {
+            const uint4* ct = cuts + (size_t)(trow * tiles_x + tile_x) * (K1_CUT_MAX + 1);
+            const uint4 hdr = ct[0];
+            const uint4 ent = ct[lane <= K1_CUT_MAX ? lane : 0];
+            s_cut[lane] = ((uint32_t)lane <= hdr.w) ? ent : make_uint4(0x7bff7bffu, 0x7bff7bffu, 0x7bff7bffu, 0u);
+        }
+#endif
 #if K1_SPLIT
         // k_pix_setup ran main():237-400 for every pixel of the launch; what make_ray needs is rebuilt from its record
         pc.geomNormal = v3(0, 1, 0); pc.origin = v3(0, 0, 0); pc.tT = v3(0, 0, 0); pc.tB = v3(0, 0, 0);
@@ -807,6 +970,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
 #else
                 g_dir[k] = make_float4(rayDir.x, rayDir.y, rayDir.z, tMinRay);
 #endif
+                if (STATS && K1_CUT) nrays++;
             }
         }
 #if K1_EARLY_RETRY
@@ -817,14 +981,22 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
         VKR_STAMP(0)
 
         // ------------------------------------------------------------------ phase 2: queues
-        const uint32_t total = nvalid * (uint32_t)rayCount;
+        const uint32_t total = (sc.tri_count != 0u) ? nvalid * (uint32_t)rayCount : 0u;   // an empty scene has a root, but nothing walks it
         uint32_t retry_mask = 0;     // bit i: this pixel's ray i was re-traced (two-round form)
         (void)retry_mask;
         uint32_t nretry = 0;
         for (int round = 0; round < (K1_EARLY_RETRY ? 1 : 2); ++round) {
+#if K1_CUT
+            // entries of the tile's cut to inject the rays at (written before the fence above); 0 when there are no rays
+            const uint32_t set_size = total ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cut[0].w) : 0u;
+#else
             const uint32_t set_size = (round == 0) ? total : nretry;
+#endif
             if (set_size == 0) break;
             uint32_t next = 0, nq = 0, lq = 0, aq = 0, gnq = 0, glq = 0;      // wave-uniform
+            uint32_t half = 0;                                                // K1_CUT: which 64 rays of the item are being injected
+            const uint32_t nhalves = (total + 63u) / 64u;
+            (void)half; (void)nhalves;
             auto ray_dir = [&](uint32_t ray) -> V3 {
 #if K1_DIR_LDS
                 return V3{s_rd[3u * ray], s_rd[3u * ray + 1u], s_rd[3u * ray + 2u]};
@@ -923,7 +1095,71 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                             for (uint32_t j = (uint32_t)lane; j < m; j += 64u) s_nq[VKR_BOUND(nq + j, K1_NQ, 64)] = g_nq[VKR_BOUND(gnq + j, K1_GNQ, 128)];
                             nq += m;
                         }
-                    } else if (next < set_size) {
+                    } else if (K1_CUT ? (half < nhalves) : (next < set_size)) {
+#if K1_CUT
+                        // ---------------- inject rays at the next entries of the tile's cut: 64 rays at a time (rays 0..63 go through
+                        // all entries first, then rays 64..127 -- as many rays in flight as the root injection had), each against
+                        // the entry's box, the ones that overlap it queued at the entry's node or leaf.  Entries follow each other
+                        // until a step's worth of items waits.  A re-traced ray (early retry) is tested with its new record like
+                        // any queued item of it; its re-trace from the root is what makes it complete.
+                        const uint32_t ray0 = (uint32_t)lane + 64u * half;
+                        const bool in0 = ray0 < total;
+                        const float4 A0 = s_ra[in0 ? ray0 : 0u], B0 = s_rb[in0 ? ray0 : 0u];
+                        const float4 cut_hdr = __builtin_bit_cast(float4, s_cut[0]);    // read here: three registers less across the queue loop
+                        // t = (bound minimum + offset - origin) / direction = fma(offset, 1/d, (minimum - origin) * 1/d)
+                        const float c0x = (cut_hdr.x - A0.x) * B0.x, c0y = (cut_hdr.y - A0.y) * B0.y, c0z = (cut_hdr.z - A0.z) * B0.z;
+                        const float tb0 = in0 ? B0.w * 1.000001f : -3.0e38f;
+                        bool more;
+                        do {
+                            // four entries per turn (the list is padded with entries no ray can hit): four independent box tests
+                            // between one round of LDS reads and one round of appends
+                            const uint4 e0 = s_cut[1u + next], e1 = s_cut[2u + next], e2 = s_cut[3u + next], e3 = s_cut[4u + next];   // wave-uniform addresses
+#define VKR_CUT_TEST(H, E)                                                                                          \
+    bool H;                                                                                                         \
+    {                                                                                                               \
+        const float x0 = fma_(h_lo(E.x), B0.x, c0x), x1 = fma_(h_hi(E.y), B0.x, c0x);                               \
+        const float y0_ = fma_(h_hi(E.x), B0.y, c0y), y1_ = fma_(h_lo(E.z), B0.y, c0y);                             \
+        const float z0 = fma_(h_lo(E.y), B0.z, c0z), z1 = fma_(h_hi(E.z), B0.z, c0z);                               \
+        const float tn = vmax3(vmin2(x0, x1), vmin2(y0_, y1_), vmin2(z0, z1));                                      \
+        const float tf = vmin3(vmax2(x0, x1), vmax2(y0_, y1_), vmax2(z0, z1));                                      \
+        H = vmax2(tn, A0.w) <= vmin2(tf, tb0);                                                                      \
+    }
+                            VKR_CUT_TEST(hit0, e0) VKR_CUT_TEST(hit1, e1) VKR_CUT_TEST(hit2, e2) VKR_CUT_TEST(hit3, e3)
+#undef VKR_CUT_TEST
+                            const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1), m2 = __ballot(hit2), m3 = __ballot(hit3);
+                            const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2), n3 = (uint32_t)__popcll(m3);
+                            const bool f0 = (int)e0.w < 0, f1 = (int)e1.w < 0, f2 = (int)e2.w < 0, f3 = (int)e3.w < 0;    // wave-uniform: leaf entries
+                            const uint32_t totn = (f0 ? 0u : n0) + (f1 ? 0u : n1) + (f2 ? 0u : n2) + (f3 ? 0u : n3);
+                            const uint32_t totl = (n0 + n1) + (n2 + n3) - totn;
+                            if (STATS) { ncuttest += in0 ? (set_size - next < 4u ? set_size - next : 4u) : 0u; ncuthit += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u) + (hit2 ? 1u : 0u) + (hit3 ? 1u : 0u); }
+                            const uint32_t rhi = ray0 << SH;                            // item: ray | node index, or ray | first * 2 | count - 1 of a leaf
+                            if (nq + totn <= (uint32_t)K1_NQ && lq + totl <= (uint32_t)K1_LQ) {
+#define VKR_CUT_PUSH(H, F, M, N, E)                                                                                 \
+    if (F) { if (H) s_lq[VKR_BOUND(lq + mbcnt64(M), K1_LQ, 1u << 26)] = rhi | (E.w & 0x7fffffffu); lq += N; }        \
+    else { if (H) s_nq[VKR_BOUND(nq + mbcnt64(M), K1_NQ, 1u << 24)] = rhi | E.w; nq += N; }
+                                VKR_CUT_PUSH(hit0, f0, m0, n0, e0) VKR_CUT_PUSH(hit1, f1, m1, n1, e1)
+                                VKR_CUT_PUSH(hit2, f2, m2, n2, e2) VKR_CUT_PUSH(hit3, f3, m3, n3, e3)
+#undef VKR_CUT_PUSH
+                            } else {
+                                // rare: per entry, LDS while it fits, the wave's global stacks beyond
+#define VKR_CUT_PUSH(H, F, M, N, E)                                                                                 \
+    if (F) {                                                                                                        \
+        if (lq + N <= (uint32_t)K1_LQ) { if (H) s_lq[VKR_BOUND(lq + mbcnt64(M), K1_LQ, 1u << 26)] = rhi | (E.w & 0x7fffffffu); lq += N; }   \
+        else { if (H) g_lq[VKR_BOUND(glq + mbcnt64(M), K1_GLQ, 1u << 27)] = rhi | (E.w & 0x7fffffffu); glq += N; if (STATS) nspill += (lane == 0) ? N : 0u; }   \
+    } else {                                                                                                        \
+        if (nq + N <= (uint32_t)K1_NQ) { if (H) s_nq[VKR_BOUND(nq + mbcnt64(M), K1_NQ, 1u << 24)] = rhi | E.w; nq += N; }   \
+        else { if (H) g_nq[VKR_BOUND(gnq + mbcnt64(M), K1_GNQ, 1u << 25)] = rhi | E.w; gnq += N; if (STATS) nspill += (lane == 0) ? N : 0u; }   \
+    }
+                                VKR_CUT_PUSH(hit0, f0, m0, n0, e0) VKR_CUT_PUSH(hit1, f1, m1, n1, e1)
+                                VKR_CUT_PUSH(hit2, f2, m2, n2, e2) VKR_CUT_PUSH(hit3, f3, m3, n3, e3)
+#undef VKR_CUT_PUSH
+                            }
+                            next += 4u;
+                            more = next < set_size;
+                        } while (more && nq < K1_STEP && lq < K1_LEAF_AT && (glq | gnq) == 0u);
+                        if (!more) { next = 0u; ++half; }                               // on to the other 64 rays
+                    }
+#else
                         // ---------------- inject the next rays at the root
                         uint32_t m = set_size - next;
                         if (m > K1_INJECT) m = K1_INJECT;
@@ -935,9 +1171,11 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                         }
                         nq += m; next += m;
                     }
+#endif
                     VKR_STAMP(1)
                     if (nq == 0u) {                     // nothing left to descend: drain the leaves, then the MASK candidates
                         if (lq > 0u) do_leaf = true;
+                        else if ((glq | gnq) != 0u || (K1_CUT && half < nhalves)) continue;   // K1_CUT: entries that queued nothing, or everything went to the global stacks
                         else if (aq > 0u) { alpha_step(aq, 0u); aq = 0u; if (STATS) ph_n[2]++; VKR_STAMP(4) continue; }
                         else break;
                     }
@@ -1014,8 +1252,9 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
                 // only when LDS + global capacity could run out: n shrinks down to one item per step = strict depth-first,
                 // whose growth is bounded by 3 x tree depth (KQ_GUARD).
                 uint32_t n = nq < K1_STEP ? nq : K1_STEP;
-                if (nq + gnq + 3u * K1_STEP > (uint32_t)K1_NQ + K1_GNQ - KQ_GUARD) {            // rare
-                    const uint32_t cap = (uint32_t)K1_NQ + K1_GNQ - KQ_GUARD, used = nq + gnq;
+                // (RAYS entries are kept back for the root items of self-hit re-traces, which retry_now pushes unthrottled)
+                if (nq + gnq + 3u * K1_STEP > (uint32_t)K1_NQ + K1_GNQ - KQ_GUARD - RAYS) {            // rare
+                    const uint32_t cap = (uint32_t)K1_NQ + K1_GNQ - KQ_GUARD - RAYS, used = nq + gnq;
                     const uint32_t fit = (cap > used ? cap - used : 0u) / 3u;
                     if (n > fit) n = fit ? fit : 1u;
                 }
@@ -1099,10 +1338,17 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
         /* item: ray | node index, or ray | first * 2 | count - 1 -- a leaf reference is that plus bit 31 */          \
         s_nq[VKR_BOUND((H) ? ((L) ? il_ : in_) : K1_TRASH, K1_TRASH + 1u, 1u << 17)] = rayhi | ((R) & 0x7fffffffu);   \
     }
+#if K1_SLOT0_FIRST       // slot 0 on top of the LIFO queues (opened first) instead of slot 3: -1 % (2.224 -> 2.200 ms, same box)
+                        VKR_APPEND(h3, l3, mn3, ml3, 0u, 0u, r3)
+                        VKR_APPEND(h2, l2, mn2, ml2, cn3, cl3, r2)
+                        VKR_APPEND(h1, l1, mn1, ml1, cn3 + cn2, cl3 + cl2, r1)
+                        VKR_APPEND(h0, l0, mn0, ml0, totn - cn0, totl - cl0, r0)
+#else
                         VKR_APPEND(h0, l0, mn0, ml0, 0u, 0u, r0)
                         VKR_APPEND(h1, l1, mn1, ml1, cn0, cl0, r1)
                         VKR_APPEND(h2, l2, mn2, ml2, cn0 + cn1, cl0 + cl1, r2)
                         VKR_APPEND(h3, l3, mn3, ml3, totn - cn3, totl - cl3, r3)
+#endif
 #undef VKR_APPEND
 #else
                         if (h0 && !l0) s_nq[VKR_BOUND(nq + mbcnt64(mn0), K1_NQ, 1u << 17)] = rayhi | r0;
@@ -1188,7 +1434,13 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
             for (int i = 0; i < rayCount; ++i) {                                    // :431 in ray order
                 const uint32_t k = (uint32_t)i * nvalid + rank;
                 const float tbv = s_rb[k].w;
+#if K1_EARLY_RETRY
+                // tMin as generated: a re-trace stores max(tMin, 1e-4) (:197), and tMin >= 1e-4 already (:377,427-429), so the LDS
+                // record still holds it -- no load from the wave's global slice in this loop
+                const float tmin0 = s_ra[k].w;
+#else
                 const float tmin0 = g_dir[k].w;
+#endif
                 const float tmax = radius;
                 float vis = 1.0f;
                 if (tbv < tmax) {                                                   // a hit was committed
@@ -1233,6 +1485,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
         atomicAdd(&stats[2], (unsigned long long)cnt.tris);
         atomicAdd(&stats[3], (unsigned long long)cnt.wave_node_iters);
         atomicAdd(&stats[4], (unsigned long long)cnt.wave_tri_iters);
+        atomicAdd(&stats[6], (unsigned long long)ncuttest);
+        atomicAdd(&stats[7], (unsigned long long)ncuthit);
     }
 }
 
@@ -1278,7 +1532,25 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     }
     const int rows = (int)tiles_y * 8;
     const dim3 pgrid(((uint32_t)fp.W + 63u) / 64u, ((uint32_t)rows + 3u) / 4u);
-    k_pix_setup<<<pgrid, 256, 0, st>>>(fp, depth, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p);
+#if K1_CUT
+    static_assert(K1_SPLIT == 1 && K1_EARLY_RETRY == 1, "the entry cut reads k_pix_setup's tile bounds and leaves re-traces to the root");
+    const size_t ncut4 = (size_t)tiles_x * tiles_y * (K1_CUT_MAX + 1), nb4 = (size_t)tiles_x * tiles_y * 2u;
+    if (c->d_cuts.n < ncut4 || c->d_tile_bounds.n < nb4) {
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        if ((e = c->d_cuts.alloc(ncut4)) != hipSuccess || (e = c->d_tile_bounds.alloc(nb4)) != hipSuccess) return e;
+    }
+#endif
+    k_pix_setup<<<dim3(pgrid.x, ((uint32_t)rows + PIX_ROWS - 1u) / PIX_ROWS), 64 * PIX_ROWS, 0, st>>>(
+        fp, depth, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p, c->d_tile_bounds.p, tiles_x);
+#if K1_CUT
+    {
+        // third level of the wide tree (levels are contiguous index ranges, recorded by the collapse): k_tile_cut's first round
+        const uint32_t l2_begin = c->cut_l2_begin, l2_count = c->cut_l2_count;    // 0 nodes: descend from the root
+        k_tile_cut<<<tiles_x * tiles_y, 64, 0, st>>>(sc, tiles_x * tiles_y, c->d_tile_bounds.p, c->d_cuts.p,
+                                                     c->cut_max < (uint32_t)K1_CUT_MAX ? c->cut_max : (uint32_t)K1_CUT_MAX, c->cut_small,
+                                                     l2_begin, l2_count);
+    }
+#endif
 #endif
     k_trace_q<STATS, RB><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, n_items,
                                                         c->d_raybuf.p, c->d_tile_counter.p,
@@ -1287,7 +1559,7 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
 #else
                                                         STATS ? c->d_stats.p : nullptr
 #endif
-                                                        , c->d_pixctx.p, c->d_vis.p);
+                                                        , c->d_pixctx.p, c->d_vis.p, c->d_cuts.p);
 #if K1_SPLIT
     k_pix_resolve<<<pgrid, 256, 0, st>>>(fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p, c->d_vis.p);
 #endif

@@ -560,6 +560,12 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
 #ifndef VKR_SP_NQ
 #define VKR_SP_NQ 768
 #endif
+#ifndef VKR_SUN_SLOT_ORDER
+#define VKR_SUN_SLOT_ORDER 1   // which child slot the LIFO node queue pops first: 0 = slot 3 (round 2), 1 = slot 0, 2 = by the sun direction
+// Measured at 4K / 16 samples over the eight sign combinations of the sun direction (tools/dbg/sun_dir_sweep.py,
+// profiles/r3_sun_slot_order.txt): slot 0 first wins or ties in six (4.95 -> 3.01 ms for the reference's direction) and loses
+// 4 % and 18 % in two; choosing by the signs of the direction (2) is no better than always slot 0.
+#endif
 constexpr int SP_PIX = VKR_SP_PIX;     // pixels per chunk at most (64, 128 or 256)
 constexpr int SP_NQ = VKR_SP_NQ;
 constexpr int SP_TQ = 64 + 64 * VKR_LEAF_MAX;   // a leaf step runs with < 64 triangle items queued and adds <= 64 * VKR_LEAF_MAX
@@ -568,7 +574,7 @@ struct SunFrame {                      // written by k_sun_setup, read with scal
     float dir[16][4];                  // sample directions (pbr.frag:255), w unused
     float idlo[4], idhi[4];            // per axis: bounds of 1/d over the samples (valid where axis_ok)
     uint32_t axis_ok[4];               // all samples have the same non-zero sign on this axis
-    uint32_t n, hard, no_light, pad;
+    uint32_t n, hard, no_light, slot0_first;   // slot0_first: open the child slots in Morton order (else in reverse)
     float axis[4];                     // cone around the samples: unit axis (= normalize(L)), w = tan of the half angle, padded
 };
 
@@ -608,7 +614,10 @@ __global__ void k_sun_setup(V3 L, float sunRadius, float sampleCountF, SunFrame*
         out->idhi[a] = h + __builtin_fabsf(h) * 1e-6f;
     }
     out->axis_ok[3] = 0; out->idlo[3] = 0; out->idhi[3] = 0;
-    out->n = (uint32_t)n; out->hard = hard ? 1u : 0u; out->no_light = no_light ? 1u : 0u; out->pad = 0;
+    out->n = (uint32_t)n; out->hard = hard ? 1u : 0u; out->no_light = no_light ? 1u : 0u;
+    // Morton order runs from low to high coordinates: front to back for a direction whose components are mostly positive
+    const int negs = (rayDir.x < 0.0f ? 1 : 0) + (rayDir.y < 0.0f ? 1 : 0) + (rayDir.z < 0.0f ? 1 : 0);
+    out->slot0_first = (VKR_SUN_SLOT_ORDER == 2) ? (negs <= 1 ? 1u : 0u) : (uint32_t)VKR_SUN_SLOT_ORDER;
     // bounding cone of the n directions (leaf pre-filter): tan of the largest angle to the axis, from the perpendicular part
     float tan_max = 0.0f;
     for (int k = 0; k < n; ++k) {
@@ -642,7 +651,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
     const char* tri_base = (const char*)sc.tris;
     const uint32_t n_dirs = sf->n;
     const uint32_t full = (n_dirs >= 32u) ? 0xffffffffu : ((1u << n_dirs) - 1u);
-    const bool hard = sf->hard != 0u, no_light = sf->no_light != 0u;
+    const bool hard = sf->hard != 0u, no_light = sf->no_light != 0u, slot0_first = sf->slot0_first != 0u;
     const float tmin = 0.001f, tmax = 500.0f;                                    // :203-204
     const float tb = tmax * 1.000001f;
     const bool okx = sf->axis_ok[0] != 0u, oky = sf->axis_ok[1] != 0u, okz = sf->axis_ok[2] != 0u;
@@ -849,7 +858,11 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
         nq += (uint32_t)__popcll(mn); lq += (uint32_t)__popcll(ml);                                                 \
     }
             VKR_PRIO_HI
-            VKR_APPEND(h0, r0) VKR_APPEND(h1, r1) VKR_APPEND(h2, r2) VKR_APPEND(h3, r3)
+            // Any-hit rays end at the first occluder, so the order the children are opened in matters (round 2 lost 44 % of this
+            // kernel when the builder put the child slots in Morton order and this step kept opening slot 3 first).  The queue is
+            // LIFO, so the slot that should be opened first is appended last (wave-uniform branch on a constant of k_sun_setup).
+            if (slot0_first) { VKR_APPEND(h3, r3) VKR_APPEND(h2, r2) VKR_APPEND(h1, r1) VKR_APPEND(h0, r0) }
+            else { VKR_APPEND(h0, r0) VKR_APPEND(h1, r1) VKR_APPEND(h2, r2) VKR_APPEND(h3, r3) }
 #undef VKR_APPEND
         }
         VKR_PRIO_LO

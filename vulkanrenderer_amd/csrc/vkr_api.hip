@@ -124,6 +124,8 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     if (const char* e = getenv("VKR_REFIT")) c->refit_wide = (e[0] != 'b');             // "binary" = k_fit + k_wide_refit
     if (const char* e = getenv("VKR_SUN_RESERVE_WAVES")) { int v = atoi(e); c->sun_reserve_waves = v < 0 ? 0 : (v > 16 ? 16 : v); }
     if (const char* e = getenv("VKR_VALIDATE_TREE")) c->validate_tree = (e[0] == '1');
+    if (const char* e = getenv("VKR_CUT_MAX")) { int v = atoi(e); c->cut_max = v < 1 ? 1u : (uint32_t)v; }   // 1 = every ray enters at the root's children
+    if (const char* e = getenv("VKR_CUT_SMALL")) { float v = (float)atof(e); if (v > 0.0f) c->cut_small = v; }
     if (const char* e = getenv("VKR_ATROUS")) c->atrous_mode = !strcmp(e, "gather") ? 0 : (!strcmp(e, "tol") ? 2 : 1);
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
     if (const char* e = getenv("VKR_SUN_MODE")) c->sun_packets = (e[0] != 'r');         // "ray" = one queue item per ray
@@ -166,7 +168,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_wide_ctl.release(); c->d_wide_bin.release(); c->d_wide_bref.release();
     for (int i = 0; i < 2; ++i) { c->d_keys[i].release(); c->d_vals[i].release(); c->d_hist_img[i].release(); c->d_ping[i].release(); }
     c->d_hist.release(); c->d_digit_totals.release(); c->d_bounds.release(); c->d_height.release();
-    c->d_nz.release(); c->d_stats.release(); c->d_raybuf.release(); c->d_pixctx.release(); c->d_vis.release();
+    c->d_nz.release(); c->d_stats.release(); c->d_raybuf.release(); c->d_pixctx.release(); c->d_vis.release(); c->d_cuts.release(); c->d_tile_bounds.release();
     c->d_normals.release(); c->d_mesh_has_normals.release(); c->d_graph.release(); c->d_tile_counter.release();
     c->d_sun_frame.release(); c->d_sun_counter.release(); c->d_shq_raybuf.release(); c->d_shq_counter.release(); c->d_comm_send.release(); c->d_comm_recv.release();
     c->d_ib_parent.release(); c->d_ib_local.release(); c->d_ib_world.release(); c->d_ib_slots.release();
@@ -365,13 +367,17 @@ int vkr_bvh_build(vkr_ctx* c, void* stream)
     c->bvh_height = 0;
     c->wide_count = 0;
     c->wide_levels = 0;
+    c->cut_l2_begin = c->cut_l2_count = 0;
     if (c->tri_count == 0) {
-        // empty scene (RayTracingContext::init with no instances): a root whose four slots are all unused, stored
-        // inverted (qmin = 255, qmax = 0, unit scale) so every slab test fails by itself and all rays miss
+        // empty scene (RayTracingContext::init with no instances): a root whose four slots are all unused, in the wide-node
+        // layout of traverse.hpp -- origin 0, the three scales 1.0f (q0.w = scale_z, q2.z = scale_x, q2.w = scale_y), planes
+        // stored inverted (qmin = 255, qmax = 0) so every slab test fails by itself.  The traversal kernels do not rely on
+        // that alone: they never walk a tree of zero triangles (sc.tri_count == 0 is checked before a root item is queued).
         const uint32_t none = (uint32_t)VKR_CHILD_NONE;
-        const uint32_t root[16] = {0u, 0u, 0u, 127u | (127u << 8) | (127u << 16),
+        const uint32_t one = 0x3f800000u;
+        const uint32_t root[16] = {0u, 0u, 0u, one,
                                    0xffffffffu, 0xffffffffu, 0xffffffffu, 0u,
-                                   0u, 0u, 0u, 0u, none, none, none, none};
+                                   0u, 0u, one, one, none, none, none, none};
         HIP_OR_FAIL(c, hipMemcpyAsync(c->d_nodes.p, root, sizeof(root), hipMemcpyHostToDevice, st));
         HIP_OR_FAIL(c, hipStreamSynchronize(st));
         c->has_bvh = true;
@@ -405,7 +411,27 @@ int vkr_bvh_build(vkr_ctx* c, void* stream)
         c->wide_level_start.clear();
         if (c->wide_levels <= 70u) c->wide_level_start.assign(ctl + 4, ctl + 4 + c->wide_levels + 1u);
         // near-first traversal defers at most 3 children per level
-        if (3u * c->wide_levels + 1u <= (uint32_t)VKR_MAX_STACK) { c->has_bvh = true; return VKR_OK; }
+        if (3u * c->wide_levels + 1u <= (uint32_t)VKR_MAX_STACK) {
+            // K1's entry cut may start at the third level when the two levels above it hold no leaf (a leaf up there is a cut
+            // entry of its own, which only the descent from the root finds): look at the root and its children once
+            c->cut_l2_begin = c->cut_l2_count = 0;
+            if (c->wide_level_start.size() >= 4u && c->wide_level_start[2] <= 5u) {
+                const uint32_t n_top = c->wide_level_start[2];          // nodes of levels 0 and 1
+                uint32_t top[5 * 16];
+                HIP_OR_FAIL(c, hipMemcpyAsync(top, c->d_nodes.p, (size_t)n_top * 64u, hipMemcpyDeviceToHost, st));
+                HIP_OR_FAIL(c, hipStreamSynchronize(st));
+                bool leaf_up_there = false;
+                for (uint32_t nd = 0; nd < n_top; ++nd)
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t ref = top[nd * 16u + 12u + (uint32_t)k];
+                        if (ref != (uint32_t)VKR_CHILD_NONE && (ref & 0x80000000u)) leaf_up_there = true;
+                    }
+                const uint32_t cnt = c->wide_level_start[3] - c->wide_level_start[2];
+                if (!leaf_up_there && cnt >= 1u && cnt <= 16u) { c->cut_l2_begin = c->wide_level_start[2]; c->cut_l2_count = cnt; }
+            }
+            c->has_bvh = true;
+            return VKR_OK;
+        }
     }
     return fail(c, VKR_ERR_LIMIT, "BVH depth %u levels exceeds the traversal stack (%d entries)", c->wide_levels,
                 VKR_MAX_STACK);
@@ -956,7 +982,7 @@ int vkr_trace_stats_get(vkr_ctx* c, vkr_trace_stats* out, int reset)
         static const char* names[8] = {"raygen", "inject", "node_steps", "leaf_steps", "alpha_steps", "retry_list", "resolve", "tile_pull"};
         fprintf(stderr, "{\"k1_phase_cycles\": {");
         for (int k = 0; k < 8; ++k) fprintf(stderr, "\"%s\": %llu, ", names[k], h[8 + k]);
-        fprintf(stderr, "\"n_node_steps\": %llu, \"n_leaf_steps\": %llu, \"n_alpha_steps\": %llu, \"node_items\": %llu, \"waves\": %llu, \"spilled_items\": %llu, \"setup_pixel\": %llu, \"visibility_loop\": %llu, \"bound_violation_bits\": %llu}}\n", h[16], h[17], h[18], h[19], h[20], h[5], h[21], h[22], h[23]);
+        fprintf(stderr, "\"n_node_steps\": %llu, \"n_leaf_steps\": %llu, \"n_alpha_steps\": %llu, \"node_items\": %llu, \"waves\": %llu, \"spilled_items\": %llu, \"setup_pixel\": %llu, \"visibility_loop\": %llu, \"bound_violation_bits\": %llu, \"cut_box_tests\": %llu, \"cut_hits\": %llu}}\n", h[16], h[17], h[18], h[19], h[20], h[5], h[21], h[22], h[23], h[6], h[7]);
     }
     out->overflow_tiles = h[5];
     out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
