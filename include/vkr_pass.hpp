@@ -133,22 +133,46 @@ struct RtaoFrameInputs {
     bool spatialDenoise = true;              // AppConfig::ENABLE_RTAO_SPATIAL_DENOISE (RtaoComputePass.cpp:529)
 };
 
+// The synchronisation half of the pass.  In the reference beginPass records three image barriers that make the prepass
+// attachments readable by the compute stage -- depth (late fragment tests -> compute), normal and linearDepth (colour
+// attachment output -> compute), RtaoComputePass.cpp:27-100 -- and endPass hands rtao_full to the fragment stage and returns
+// the three attachments to their attachment layouts (:158-255).  On the HIP side there are no layouts; what is left of those
+// barriers is ordering between the host's Vulkan queue and the HIP stream, which only the host can express (it owns the
+// exported timeline semaphore / the events).  The adapter therefore takes two callables and runs them exactly where the
+// reference records its barriers:
+//   beforePass(ectx, stream): make `stream` wait until the prepass has written linearDepth / normal
+//                             (hipWaitExternalSemaphoresAsync on the semaphore the prepass submit signals, or hipStreamWaitEvent)
+//   afterPass(ectx, stream):  publish rtao_full to the consumer (hipSignalExternalSemaphoresAsync, which the ScenePass
+//                             submit waits on at the fragment stage, or hipEventRecord) -- and, by the same signal, tell
+//                             the host that linearDepth / normal may be attachments again
+// Both are optional; an empty hook is the single-stream case, where stream order already is the barrier.
+template <class ExecuteContext>
+struct RtaoPassSync {
+    std::function<void(const ExecuteContext&, void* stream)> beforePass;   // RtaoComputePass::beginPass, RtaoComputePass.cpp:27-100
+    std::function<void(const ExecuteContext&, void* stream)> afterPass;    // RtaoComputePass::endPass,   RtaoComputePass.cpp:158-255
+};
+
 template <class RenderPassBase, class ExecuteContext>
 class HipRtaoPass : public RenderPassBase {
 public:
     using InputProvider = std::function<RtaoFrameInputs(const ExecuteContext&)>;
+    using Sync = RtaoPassSync<ExecuteContext>;
 
-    HipRtaoPass(HipContext& context, InputProvider provider)
+    HipRtaoPass(HipContext& context, InputProvider provider, Sync sync = Sync{})
         : RenderPassBase("RtaoComputePass", {"depth"}, {"rtao_full"}),   // RtaoComputePass.cpp:16-25
-          ctx_(context.get()), provider_(std::move(provider))
+          ctx_(context.get()), provider_(std::move(provider)), sync_(std::move(sync))
     {
     }
 
 protected:
-    void beginPass(const ExecuteContext&) override {}                     // RtaoComputePass.cpp:98-100 (empty)
-    void render(const ExecuteContext& ectx) override                      // RtaoComputePass.cpp:102-156
+    void beginPass(const ExecuteContext& ectx) override                   // RtaoComputePass.cpp:27-100: the three acquire barriers
     {
-        RtaoFrameInputs in = provider_(ectx);
+        in_ = provider_(ectx);                                            // the frame's inputs, once per execute()
+        if (sync_.beforePass) sync_.beforePass(ectx, in_.stream);
+    }
+    void render(const ExecuteContext&) override                           // RtaoComputePass.cpp:102-156
+    {
+        const RtaoFrameInputs& in = in_;
         if (!in.enableRtao) return;                                       // :104-106
         if (!in.ubo) throw std::runtime_error("HipRtaoPass: ubo is null");
         vkr_rtao_frame_io io{};
@@ -160,11 +184,16 @@ protected:
         io.ray_hit_mask = nullptr;
         check(ctx_, vkr_rtao_execute(ctx_, &io, in.stream), "vkr_rtao_execute");
     }
-    void endPass(const ExecuteContext&) override {}                       // RtaoComputePass.cpp:158-160 (empty)
+    void endPass(const ExecuteContext& ectx) override                     // RtaoComputePass.cpp:158-255: release rtao_full + the attachments
+    {
+        if (sync_.afterPass) sync_.afterPass(ectx, in_.stream);
+    }
 
 private:
     vkr_ctx* ctx_;
     InputProvider provider_;
+    Sync sync_;
+    RtaoFrameInputs in_{};
 };
 
 }  // namespace vkr

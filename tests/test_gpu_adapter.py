@@ -42,6 +42,8 @@ def test_cpp_adapter_matches_python_host(tmp_path):
     r = subprocess.run([DEMO, str(blob), str(out)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok ")
+    # the pass ran its beforePass / afterPass hooks once per frame (two streams ordered by events: RtaoComputePass.cpp:27-100,158-255)
+    assert f"hooks={frames}+{frames}" in r.stdout
     got = np.fromfile(out, dtype=np.uint16).reshape(H, W)
 
     ctx = Context(W, H)

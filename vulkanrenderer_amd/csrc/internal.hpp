@@ -163,6 +163,10 @@ struct vkr_ctx {
     int atrous_mode = 1;                     // K2 form: 1 LDS-tiled (default), 0 per-pixel gathers (VKR_ATROUS=gather), 2 tiled + v_exp_f32 (VKR_ATROUS=tol, outside the bit-exact contract)
     bool trace_streaming = true;             // K1 form: wave-wide queues (k_trace_q) or one ray per lane (k_trace)
     int num_cus = 0;
+    int k1_per_cu[2][3] = {{0, 0, 0}, {0, 0, 0}};   // resident k_trace_q workgroups per CU, [STATS][RB - 6]; 0 = not asked yet
+    int sun_per_cu = 0, shq_per_cu[2] = {0, 0};     // the same for k_shadow_sun_pkt and k_shadow_q<0/1>
+    int q_ray_bits_override = 0;                    // VKR_Q_RAY_BITS (tests)
+    int k1_extra_lds = 0;                           // VKR_K1_EXTRA_LDS (development)
     vkr::DevBuf<float4> d_pixctx;            // K1_SPLIT: 3 float4 per pixel from k_pix_setup (rtao_kernels.hip)
     vkr::DevBuf<float2> d_vis;               // K1_SPLIT: summed visibility + hit bits per pixel, k_trace_q -> k_pix_resolve
     vkr::DevBuf<float4> d_tile_bounds;       // K1_CUT: per 8x8 tile of a launch, the bound of its ray segments (k_pix_setup -> k_tile_cut)
@@ -230,6 +234,8 @@ hipError_t fill_r16f_launch(uint16_t* img, size_t count, float value, hipStream_
 hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
                              const float L[3], float radius, float samples, float* out, hipStream_t st);
 hipError_t noalloc_scratch_init(int device);
+hipError_t shadow_prepare(vkr_ctx* c);
+hipError_t rtao_prepare(vkr_ctx* c, hipStream_t st);
 hipError_t shadow_sun_noalloc_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
                                      const float L[3], float radius, float samples, float* out, hipStream_t st);
 hipError_t shadow_point_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,

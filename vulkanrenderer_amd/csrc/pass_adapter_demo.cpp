@@ -40,21 +40,31 @@ protected:
     std::vector<std::string> inputs, outputs;
 };
 
-// stands in for DepthPrepass: outputs {"depth","normal"}
+// stands in for DepthPrepass: outputs {"depth","normal"}.  It runs on its own stream (the host's graphics queue); the two
+// events are the demo's stand-in for the exported timeline semaphore of INTEGRATION.md: `written` is what the RTAO pass waits
+// on before it reads the attachments, `released` is what it signals once it no longer needs them.
 class GBufferPass : public RenderPass {
 public:
-    GBufferPass(vkr_ctx* c, uint16_t* depth, uint16_t* normal)
-        : RenderPass("DepthPrepass", {}, {"depth", "normal"}), ctx(c), d(depth), n(normal) {}
+    GBufferPass(vkr_ctx* c, uint16_t* depth, uint16_t* normal, hipStream_t gfx, hipEvent_t written, hipEvent_t released)
+        : RenderPass("DepthPrepass", {}, {"depth", "normal"}), ctx(c), d(depth), n(normal), st(gfx), evWritten(written), evReleased(released) {}
 
 protected:
-    void beginPass(const PassExecuteContext&) override {}
+    void beginPass(const PassExecuteContext&) override
+    {
+        if (hipStreamWaitEvent(st, evReleased, 0) != hipSuccess) throw std::runtime_error("hipStreamWaitEvent");   // last frame's reader is done
+    }
     void render(const PassExecuteContext& e) override
     {
-        vkr::check(ctx, vkr_gbuffer_primary(ctx, e.ubo, d, n, nullptr, nullptr, nullptr, e.stream), "vkr_gbuffer_primary");
+        vkr::check(ctx, vkr_gbuffer_primary(ctx, e.ubo, d, n, nullptr, nullptr, nullptr, st), "vkr_gbuffer_primary");
     }
-    void endPass(const PassExecuteContext&) override {}
+    void endPass(const PassExecuteContext&) override
+    {
+        if (hipEventRecord(evWritten, st) != hipSuccess) throw std::runtime_error("hipEventRecord");
+    }
     vkr_ctx* ctx;
     uint16_t *d, *n;
+    hipStream_t st;
+    hipEvent_t evWritten, evReleased;
 };
 
 class Rendergraph {
@@ -226,14 +236,34 @@ int main(int argc, char** argv)
         HIP_CHECK(hipMalloc((void**)&full, (size_t)W * H * 2));
         using Pass = vkr::HipRtaoPass<demo::RenderPass, demo::PassExecuteContext>;
         demo::Rendergraph graph;
+        // Two streams, like a host whose prepass runs on the graphics queue and the RTAO pass on a compute stream: the pass's
+        // beforePass / afterPass hooks (RtaoComputePass::beginPass / endPass barriers, RtaoComputePass.cpp:27-100,158-255) carry
+        // the ordering between them.  Without the hooks the two passes race; with them the output is the single-stream one.
+        hipStream_t gfx = nullptr, comp = nullptr;
+        hipEvent_t evWritten = nullptr, evReleased = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&gfx, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&comp, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&evWritten, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&evReleased, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(evReleased, comp));                       // nothing to wait for before the first frame
+        uint32_t nBefore = 0, nAfter = 0;
+        Pass::Sync sync;
+        sync.beforePass = [&](const demo::PassExecuteContext&, void* stream) {
+            ++nBefore;
+            if (hipStreamWaitEvent((hipStream_t)stream, evWritten, 0) != hipSuccess) throw std::runtime_error("hipStreamWaitEvent");
+        };
+        sync.afterPass = [&](const demo::PassExecuteContext&, void* stream) {
+            ++nAfter;
+            if (hipEventRecord(evReleased, (hipStream_t)stream) != hipSuccess) throw std::runtime_error("hipEventRecord");
+        };
         // registered out of order on purpose: Compile() must put DepthPrepass first
         graph.AddPass(std::make_unique<Pass>(context, [&](const demo::PassExecuteContext& e) {
             vkr::RtaoFrameInputs in;
-            in.ubo = e.ubo; in.linearDepth = depth; in.normal = normal; in.rtaoFull = full; in.stream = e.stream;
+            in.ubo = e.ubo; in.linearDepth = depth; in.normal = normal; in.rtaoFull = full; in.stream = comp;
             in.atrousIterations = iters;
             return in;
-        }));
-        graph.AddPass(std::make_unique<demo::GBufferPass>(context.get(), depth, normal));
+        }, sync));
+        graph.AddPass(std::make_unique<demo::GBufferPass>(context.get(), depth, normal, gfx, evWritten, evReleased));
         graph.Compile();
         auto names = graph.orderNames();
         if (names.size() != 2 || names[0] != "DepthPrepass" || names[1] != "RtaoComputePass") { fprintf(stderr, "bad pass order\n"); return 4; }
@@ -243,7 +273,9 @@ int main(int argc, char** argv)
             e.imageIndex = fr & 1u;
             graph.Execute(e);
         }
-        vkr::check(context.get(), vkr_sync(context.get(), nullptr), "vkr_sync");
+        vkr::check(context.get(), vkr_sync(context.get(), comp), "vkr_sync");
+        vkr::check(context.get(), vkr_sync(context.get(), gfx), "vkr_sync");
+        if (nBefore != frames || nAfter != frames) { fprintf(stderr, "pass hooks ran %u/%u times for %u frames\n", nBefore, nAfter, frames); return 5; }
         std::vector<uint16_t> out((size_t)W * H);
         HIP_CHECK(hipMemcpy(out.data(), full, out.size() * 2, hipMemcpyDeviceToHost));
         FILE* o = fopen(argv[2], "wb");
@@ -251,8 +283,9 @@ int main(int argc, char** argv)
         fwrite(out.data(), 2, out.size(), o);
         fclose(o);
         vkr_bvh_info info = rt.info();
-        printf("ok %ux%u frames=%u triangles=%u nodes=%u\n", W, H, frames, info.triangle_count, info.node_count);
+        printf("ok %ux%u frames=%u triangles=%u nodes=%u hooks=%u+%u\n", W, H, frames, info.triangle_count, info.node_count, nBefore, nAfter);
         (void)hipFree(depth); (void)hipFree(normal); (void)hipFree(full);
+        (void)hipEventDestroy(evWritten); (void)hipEventDestroy(evReleased); (void)hipStreamDestroy(gfx); (void)hipStreamDestroy(comp);
     } catch (const std::exception& ex) {
         fprintf(stderr, "error: %s\n", ex.what());
         return 1;

@@ -1496,7 +1496,7 @@ static int q_ray_bits(const vkr_ctx* c)
 {
     for (int rb = K1_RB; rb >= 6; --rb)
         if ((uint64_t)c->tri_count * 2u <= (1ull << (32 - rb)) && (uint64_t)c->wide_count <= (1ull << (32 - rb))) {
-            if (const char* e = getenv("VKR_Q_RAY_BITS")) { int v = atoi(e); if (v >= 6 && v < rb) return v; }   // tests: force a narrower item
+            if (c->q_ray_bits_override >= 6 && c->q_ray_bits_override < rb) return c->q_ray_bits_override;   // VKR_Q_RAY_BITS (tests: a narrower item)
             return rb;
         }
     return 0;
@@ -1509,11 +1509,14 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     hipError_t e;
     const uint32_t n_items = tiles_x * tiles_y * (64u / (uint32_t)q_item_pixels(RB, fp.rayCount));
     // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
-    size_t lds = q_lds_bytes(RB);
-    if (const char* x = getenv("VKR_K1_EXTRA_LDS")) lds += (size_t)atoi(x);   // development: occupancy experiments
-    int per_cu = 0;
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<STATS, RB>, K1_BLOCK, lds)) != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    const size_t lds = q_lds_bytes(RB) + (size_t)c->k1_extra_lds;            // VKR_K1_EXTRA_LDS: occupancy experiments (development)
+    // resident workgroups per CU: asked of the runtime once per kernel instance and context, not per frame (a frame makes no
+    // host query, allocation or synchronisation once its buffers exist: vkr_rtao_execute can be captured into a HIP graph)
+    int& per_cu = c->k1_per_cu[STATS ? 1 : 0][RB - 6];
+    if (per_cu == 0) {
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<STATS, RB>, K1_BLOCK, lds)) != hipSuccess) { per_cu = 0; return e; }
+        if (per_cu < 1) per_cu = 1;
+    }
     uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
     if (blocks > n_items) blocks = n_items;
     const size_t need = (size_t)blocks * q_slice_layout(RB).total_f4;
@@ -1564,6 +1567,49 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     k_pix_resolve<<<pgrid, 256, 0, st>>>(fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p, c->d_vis.p);
 #endif
     return hipGetLastError();
+}
+
+// What a frame would otherwise ask of the runtime on its first launch -- the occupancy of the persistent kernel and its
+// scratch for a full-height launch -- done once per build (vkr_bvh_build), so that the frame calls only enqueue work.  The
+// grow-only checks in trace_q_launch stay as the safety net (a STATS launch, a tree that changed its item width).
+hipError_t rtao_prepare(vkr_ctx* c, hipStream_t st)
+{
+    const int rb = c->trace_streaming ? q_ray_bits(c) : 0;
+    if (rb == 0) return hipSuccess;
+    hipError_t e;
+    const size_t lds = q_lds_bytes(rb) + (size_t)c->k1_extra_lds;
+    int& per_cu = c->k1_per_cu[0][rb - 6];
+    if (per_cu == 0) {
+#if K1_RB >= 8
+        if (rb == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 8>, K1_BLOCK, lds); else
+#endif
+#if K1_RB >= 7
+        if (rb == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 7>, K1_BLOCK, lds); else
+#endif
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 6>, K1_BLOCK, lds);
+        if (e != hipSuccess) { per_cu = 0; return e; }
+        if (per_cu < 1) per_cu = 1;
+    }
+    const size_t blocks = (size_t)per_cu * (size_t)(c->num_cus > 0 ? c->num_cus : 256);
+    const size_t need = blocks * q_slice_layout(rb).total_f4;
+    const size_t npx = (size_t)c->W * c->H;
+    const size_t tiles = (size_t)((c->W + 7u) / 8u) * ((c->H + 7u) / 8u + 1u);     // a band that starts between tile rows has one row more
+    constexpr uint32_t n_ctr = 16u * (K1_SLABS > 8 ? K1_SLABS : 8);
+    const bool grow = c->d_raybuf.n < need || c->d_tile_counter.n < n_ctr || (K1_SPLIT && (c->d_pixctx.n < 3u * npx || c->d_vis.n < npx)) ||
+                      (K1_CUT && (c->d_cuts.n < tiles * (K1_CUT_MAX + 1) || c->d_tile_bounds.n < tiles * 2u));
+    if (!grow) return hipSuccess;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (c->d_raybuf.n < need && (e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
+    if (c->d_tile_counter.n < n_ctr && (e = c->d_tile_counter.alloc(n_ctr)) != hipSuccess) return e;
+#if K1_SPLIT
+    if (c->d_pixctx.n < 3u * npx && (e = c->d_pixctx.alloc(3u * npx)) != hipSuccess) return e;
+    if (c->d_vis.n < npx && (e = c->d_vis.alloc(npx)) != hipSuccess) return e;
+#endif
+#if K1_CUT
+    if (c->d_cuts.n < tiles * (K1_CUT_MAX + 1) && (e = c->d_cuts.alloc(tiles * (K1_CUT_MAX + 1))) != hipSuccess) return e;
+    if (c->d_tile_bounds.n < tiles * 2u && (e = c->d_tile_bounds.alloc(tiles * 2u)) != hipSuccess) return e;
+#endif
+    return hipSuccess;
 }
 
 hipError_t rtao_trace_launch(vkr_ctx* c, const FrameParams& fp, const uint16_t* depth, const uint16_t* hist_prev,

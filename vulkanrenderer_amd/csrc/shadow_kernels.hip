@@ -890,11 +890,13 @@ static hipError_t shadow_q_launch(vkr_ctx* c, int mode, const ShadowArgs& sa, hi
     hipError_t e;
     const uint32_t per = mode == 0 ? 64u : (uint32_t)SQ_POINT_PIX;
     const uint32_t n_chunks = (sa.count + per - 1u) / per;
-    int per_cu = 0;
-    if (mode == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_q<0>, 64, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_q<1>, 64, 0);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    int& per_cu = c->shq_per_cu[mode == 0 ? 0 : 1];      // asked of the runtime once per context, not per call
+    if (per_cu == 0) {
+        if (mode == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_q<0>, 64, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_q<1>, 64, 0);
+        if (e != hipSuccess) { per_cu = 0; return e; }
+        if (per_cu < 1) per_cu = 1;
+    }
     uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
     if (blocks > n_chunks) blocks = n_chunks;
     const size_t need = mode == 0 ? 1 : (size_t)blocks * SQ_POINT_PIX * 3;
@@ -922,9 +924,11 @@ hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const
             if (!c->d_sun_frame.p && (e = c->d_sun_frame.alloc(sizeof(SunFrame))) != hipSuccess) return e;
             SunFrame* sf = (SunFrame*)c->d_sun_frame.p;
             k_sun_setup<<<1, 64, 0, st>>>(sa.L, radius, samples, sf);
-            int per_cu = 0;
-            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) return e;
-            if (per_cu < 1) per_cu = 1;
+            if (c->sun_per_cu == 0) {                         // asked of the runtime once per context, not per call
+                if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
+                if (c->sun_per_cu < 1) c->sun_per_cu = 1;
+            }
+            int per_cu = c->sun_per_cu;
             // Wave slots per CU this persistent launch leaves free (4; VKR_SUN_RESERVE_WAVES).  A full launch holds 456 of the
             // 512 VGPRs of every SIMD until its last chunk is done: a kernel issued while it runs -- the A-Trous launches of
             // the same frame on another stream, a collective's kernel of a multi-GPU host -- would wait for exactly that.
@@ -989,9 +993,11 @@ hipError_t shadow_sun_noalloc_launch(vkr_ctx* c, const float* wp, const float* n
     ShadowArgs sa{wp, ng, valid, count, V3{L[0], L[1], L[2]}, radius, samples, V3{0, 0, 0}, out, nullptr};
     if ((e = hipMemsetAsync(counter, 0, 256, st)) != hipSuccess) return e;      // the last call left its chunk count here
     k_sun_setup<<<1, 64, 0, st>>>(sa.L, radius, samples, sf);
-    int per_cu = 0;
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    if (c->sun_per_cu == 0) {                                 // normally known since vkr_bvh_build (shadow_prepare)
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
+        if (c->sun_per_cu < 1) c->sun_per_cu = 1;
+    }
+    int per_cu = c->sun_per_cu;
     if (c->sun_reserve_waves > 0) per_cu = per_cu > c->sun_reserve_waves ? per_cu - c->sun_reserve_waves : 1;
     uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
     uint32_t pix = (uint32_t)SP_PIX;                      // same chunking as shadow_sun_launch
@@ -1000,6 +1006,21 @@ hipError_t shadow_sun_noalloc_launch(vkr_ctx* c, const float* wp, const float* n
     if (blocks > n_chunks) blocks = n_chunks;
     k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, counter);
     return hipGetLastError();
+}
+
+// Everything a shadow launch asks of the runtime besides the launch itself -- occupancy of the persistent kernels, the chunk
+// counters, the sun's direction table -- once per build, so that the per-frame calls only enqueue work.
+hipError_t shadow_prepare(vkr_ctx* c)
+{
+    hipError_t e;
+    if (c->sun_per_cu == 0) {
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
+        if (c->sun_per_cu < 1) c->sun_per_cu = 1;
+    }
+    if (!c->d_sun_frame.p && (e = c->d_sun_frame.alloc(sizeof(SunFrame))) != hipSuccess) return e;
+    if (!c->d_sun_counter.p && (e = c->d_sun_counter.alloc(8)) != hipSuccess) return e;
+    if (!c->d_shq_counter.p && (e = c->d_shq_counter.alloc(1)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 hipError_t shadow_point_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,

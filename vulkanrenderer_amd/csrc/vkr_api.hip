@@ -124,6 +124,8 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     if (const char* e = getenv("VKR_REFIT")) c->refit_wide = (e[0] != 'b');             // "binary" = k_fit + k_wide_refit
     if (const char* e = getenv("VKR_SUN_RESERVE_WAVES")) { int v = atoi(e); c->sun_reserve_waves = v < 0 ? 0 : (v > 16 ? 16 : v); }
     if (const char* e = getenv("VKR_VALIDATE_TREE")) c->validate_tree = (e[0] == '1');
+    if (const char* e = getenv("VKR_Q_RAY_BITS")) c->q_ray_bits_override = atoi(e);
+    if (const char* e = getenv("VKR_K1_EXTRA_LDS")) { int v = atoi(e); c->k1_extra_lds = v < 0 ? 0 : v; }
     if (const char* e = getenv("VKR_CUT_MAX")) { int v = atoi(e); c->cut_max = v < 1 ? 1u : (uint32_t)v; }   // 1 = every ray enters at the root's children
     if (const char* e = getenv("VKR_CUT_SMALL")) { float v = (float)atof(e); if (v > 0.0f) c->cut_small = v; }
     if (const char* e = getenv("VKR_ATROUS")) c->atrous_mode = !strcmp(e, "gather") ? 0 : (!strcmp(e, "tol") ? 2 : 1);
@@ -430,6 +432,10 @@ int vkr_bvh_build(vkr_ctx* c, void* stream)
                 if (!leaf_up_there && cnt >= 1u && cnt <= 16u) { c->cut_l2_begin = c->wide_level_start[2]; c->cut_l2_count = cnt; }
             }
             c->has_bvh = true;
+            // occupancy queries and per-frame scratch of the traversal kernels: here, once, so that the frame calls neither ask
+            // the runtime anything nor allocate (and can be captured into a HIP graph)
+            HIP_OR_FAIL(c, rtao_prepare(c, st));
+            HIP_OR_FAIL(c, shadow_prepare(c));
             return VKR_OK;
         }
     }

@@ -404,6 +404,20 @@ class RtaoComputePass(RenderPass):
         self.hit_mask = (torch.zeros((ctx.height, ctx.width), dtype=torch.int32, device=ctx.device)
                          if want_hit_mask else None)
         self.band = None      # (y0, y1) for row-band sharding, None = full frame
+        # The synchronisation half of the pass (RtaoComputePass::beginPass / endPass record the image barriers around the three
+        # dispatches, RtaoComputePass.cpp:27-100,158-255).  On HIP what is left of them is ordering against the producer of the
+        # G-buffer and the consumer of rtao_full when those run on other streams / queues: two optional callables
+        # (pass_ctx, stream), run where the reference records its barriers -- same contract as include/vkr_pass.hpp.
+        self.before_pass = None
+        self.after_pass = None
+
+    def beginPass(self, pctx: PassExecuteContext):
+        if self.before_pass is not None:
+            self.before_pass(pctx, pctx.stream or self.ctx.stream())
+
+    def endPass(self, pctx: PassExecuteContext):
+        if self.after_pass is not None:
+            self.after_pass(pctx, pctx.stream or self.ctx.stream())
 
     def _io(self, ubo: np.ndarray) -> _capi.RtaoFrameIO:
         io = _capi.RtaoFrameIO()
