@@ -293,6 +293,12 @@ def _hip_runtime():
     return hip
 
 
+def fs_pose_ubo(W, H, rays, sun_samples, pose):
+    """A UBO for generating the G-buffer of one camera pose (the producer reads view / proj / camPos only)."""
+    from vulkanrenderer_amd import FrameState
+    return FrameState(W, H, ray_count=rays, sun_samples=max(1, sun_samples)).update(*pose)
+
+
 def main():
     args = parse_args()
     if args.workload == "c1":
@@ -351,13 +357,21 @@ def main():
     build_ms = min(event_time_ms(rt.rebuild, None) for _ in range(3))
 
     fs = FrameState(W, H, ray_count=rays, sun_samples=max(1, sun_samples))
-    path = camera_path(scene, frames, step=0.05)
-    ubos = [fs.update(e, t) for e, t in path]
-    gbs = []
-    for i in range(frames):
+    # N = 1: one G-buffer per frame along a straight dolly (resident before the timed region).  N > 1 (4K): a 4K G-buffer with
+    # its shading inputs is 290 MB, so only RESIDENT camera poses are kept and the camera dollies forth and back over them
+    # (0 1 2 3 2 1 0 1 ...): the motion stays continuous -- every frame's prevViewProj is the pose rendered before it -- and
+    # a rank holds 1.2 GB of inputs instead of 7 GB.
+    resident = frames if n == 1 else max(2, min(frames, int(os.environ.get("VKR_BENCH_RESIDENT_GBUFFERS", "4"))))
+    poses = camera_path(scene, resident, step=0.05)
+    period = max(1, 2 * (resident - 1))
+    pose_of = [i if n == 1 else ((i % period) if (i % period) < resident else period - (i % period)) for i in range(frames)]
+    ubos = [fs.update(*poses[pose_of[i]]) for i in range(frames)]
+    pose_gbs = []
+    for k in range(resident):
         gb = GBuffer(ctx, with_shading_inputs=(sun_samples > 0))
-        generate_gbuffer(ctx, ubos[i], gb)
-        gbs.append(gb)
+        generate_gbuffer(ctx, fs_pose_ubo(W, H, rays, sun_samples, poses[k]), gb)
+        pose_gbs.append(gb)
+    gbs = [pose_gbs[pose_of[i]] for i in range(frames)]
     ctx.sync()
 
     log("G-buffers ready")
@@ -378,7 +392,10 @@ def main():
     # VKR_BENCH_CAPI_COMM=1: the same schedule with both gathers behind the C boundary (vkr_comm_attach + vkr_rtao_gather_history
     # + vkr_gather_bands: fused pack, ncclAllGather on the frame's stream, fused unpack) -- what a C++ host would run.  Under
     # RCCL the process group's own communicator is attached; in the gloo rehearsal the custom-transport hook carries it.
-    capi_comm = n > 1 and os.environ.get("VKR_BENCH_CAPI_COMM") == "1"
+    # Default for N > 1: the collective behind the C boundary (what a C++ host runs), on a communication stream of its own,
+    # ordered against the frame's stream by events, so that the history gather overlaps the sun kernel and the output gather
+    # overlaps the next frame's K1.  VKR_BENCH_TORCH_COMM=1 selects the torch.distributed gathers (index_select packing) instead.
+    capi_comm = n > 1 and os.environ.get("VKR_BENCH_TORCH_COMM") != "1"
     if capi_comm:
         if rehearse:
             def gloo_allgather(user, send, recv, nbytes, stream):
@@ -399,6 +416,8 @@ def main():
     pending = []   # the [rtao_full | sun] gather of the previous frame, still in flight on the communicator's stream
 
     def finish_output_gather():
+        if capi_comm:
+            torch.cuda.current_stream().wait_event(ev_out)
         if pending:
             work, planes = pending.pop()
             work.wait()
@@ -408,6 +427,10 @@ def main():
     # K1: its persistent waves fill the CUs as K1's waves drain, instead of the two launches each paying its own tail.
     side = torch.cuda.Stream(device=dev) if (shadows is not None and os.environ.get("VKR_BENCH_SUN_STREAM", "1") == "1") else None
     ev_sun, ev_sun_read = torch.cuda.Event(), torch.cuda.Event()
+    comm = torch.cuda.Stream(device=dev) if capi_comm else None
+    ev_k1, ev_hist, ev_dn, ev_out = (torch.cuda.Event() for _ in range(4))
+    if capi_comm:
+        ev_out.record(torch.cuda.current_stream())                             # nothing to wait for before the first frame
 
     def issue_sun(i, rows):
         shadows.gb = gbs[i]
@@ -433,18 +456,29 @@ def main():
                 ev_sun_read.record(torch.cuda.current_stream())
             return
         if capi_comm:
-            rpass.traceStripes(ubos[i], rank, n)
+            main = torch.cuda.current_stream()
+            rpass.traceStripes(ubos[i], rank, n)                               # overlaps the previous frame's output gather
+            ev_k1.record(main)
             if shadows is not None:
-                issue_sun(i, (y0, y1))
-            rpass.gatherHistory()
+                issue_sun(i, (y0, y1))                                         # side stream: fills K1's drain, then overlaps the history gather
+            comm.wait_event(ev_k1)
+            with torch.cuda.stream(comm):
+                rpass.gatherHistory()                                          # pack + ncclAllGather + unpack on the communication stream
+                ev_hist.record(comm)
+            main.wait_event(ev_out)                                            # frame i-1 is assembled before its planes are rewritten
             planes = [rpass.rtao_full]
             if shadows is not None:
                 join_sun()
                 sun16[y0:y1].copy_(shadows.sun_vis[y0:y1])
-                ev_sun_read.record(torch.cuda.current_stream())
+                ev_sun_read.record(main)
                 planes.append(sun16.view(torch.int16))
+            main.wait_event(ev_hist)                                           # A-Trous reads its halo rows from the gathered history
             rpass.denoiseBand(ubos[i], y0, y1)
-            ctx.gatherBands(planes)
+            ev_dn.record(main)
+            comm.wait_event(ev_dn)
+            with torch.cuda.stream(comm):
+                ctx.gatherBands(planes)
+                ev_out.record(comm)
             return
         rpass.traceStripes(ubos[i], rank, n)                                  # overlaps the previous frame's output gather
         if shadows is not None:
@@ -488,6 +522,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the sharded run's last frame, kept for the comparison with the unsharded replay below
+    sharded_last = None
+    if n > 1 and not args.no_extra:
+        sharded_last = (rpass.rtao_full.clone(), rpass.image(0).clone(), sun16.clone() if shadows is not None else None)
+
     # ---- untimed: count the rays of the timed frames (AO incl. retries via counters; shadow = valid px * samples)
     trace_stats_enable(ctx, True)
     trace_stats(ctx, reset=True)
@@ -516,7 +555,9 @@ def main():
                    "triangles": info.triangle_count, "instances": int(len(scene.instance_mesh)),
                    "bvh_levels": info.height, "bvh_nodes": info.node_count, "binary_height": info.binary_height, "lbvh_build_ms": build_ms,
                    "rays_per_frame": total_rays / K, "parallelism": f"rowband{n}" if n > 1 else "single",
-                   "collective": ("none" if n == 1 else "c-abi (vkr_gather_*)" if capi_comm else "torch.distributed all_gather")},
+                   "collective": ("none" if n == 1 else "c-abi (vkr_rtao_gather_history + vkr_gather_bands: fused pack, ncclAllGather, fused unpack) on a "
+                                  "communication stream" if capi_comm else "torch.distributed all_gather"),
+                   "resident_gbuffers": resident},
     }
 
     if rank == 0 and not args.no_extra and n > 1:
@@ -532,13 +573,20 @@ def main():
                 shadows.gb = gbs[i]
                 shadows.sun(ubos[i])
 
-        whole_frame(0)
+        for i in range(Wu):                                                # the same frames from the same cleared history
+            whole_frame(i)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(Wu, Wu + K):
             whole_frame(i)
         torch.cuda.synchronize()
         t1 = time.perf_counter() - t1
+        # the invariant of SURVEY 8e on the real transport: the frame the N ranks assembled == the unsharded frame, bit for bit
+        same = {"rtao_full": bool(torch.equal(sharded_last[0], rpass.rtao_full)), "history": bool(torch.equal(sharded_last[1], rpass.image(0)))}
+        if shadows is not None:
+            same["sun"] = bool(torch.equal(sharded_last[2], shadows.sun_vis.to(torch.float16)))
+        out["sharded_equals_unsharded"] = all(same.values())
+        out["sharded_equals_unsharded_planes"] = same
         out["strong_scaling_reference"] = {
             "n_gpus": 1, "ms_per_step": t1 / K * 1e3, "value": total_rays / t1 / 1e6, "unit": "Mrays/s",
             "note": "same workload and frames, unsharded, on rank 0 alone after the timed region (other ranks idle); "

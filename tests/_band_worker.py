@@ -56,6 +56,73 @@ def stripe_frame(osc, ubo, depth, normal, hist_prev, hist_curr, rank, world, pla
     return O.upsample(ubo, src, normal)
 
 
+# ---- the C-ABI collective (vulkanrenderer_amd/csrc/comm.hip) on the CPU: the index arithmetic of its four kernels, line by line,
+# with gloo carrying the bytes -- what bench.py's default N > 1 path runs per frame:
+#     vkr_rtao_trace_stripes -> vkr_rtao_gather_history -> vkr_rtao_denoise_band -> vkr_gather_bands([rtao_full, sun])
+def capi_stripes_per_rank(Hh, n):
+    return (((Hh + 7) // 8) + n - 1) // n
+
+
+def capi_pack_stripes(plane, rank, n):                       # k_pack_stripes
+    Hh = plane.shape[0]
+    j = np.arange(capi_stripes_per_rank(Hh, n) * 8)
+    row = np.minimum(((j >> 3) * n + rank) * 8 + (j & 7), Hh - 1)
+    return np.ascontiguousarray(plane[row])
+
+
+def capi_unpack_stripes(recv, plane, n):                     # k_unpack_stripes: every image row exactly once
+    row = np.arange(plane.shape[0])
+    s = row >> 3
+    plane[row] = recv[s % n, (s // n) * 8 + (row & 7)]
+
+
+def capi_pack_bands(planes, rank, n):                        # k_pack_bands: slot = [plane][Hb rows][W], pad rows stay as they are
+    Hh, Ww = planes[0].shape
+    hb = (Hh + n - 1) // n
+    send = np.full((len(planes), hb, Ww), 0x5a5a, dtype=np.uint16)
+    for k, p in enumerate(planes):
+        rows = np.arange(rank * hb, min(Hh, (rank + 1) * hb))
+        send[k, : len(rows)] = p[rows]
+    return send
+
+
+def capi_unpack_bands(recv, planes, n):                      # k_unpack_bands
+    Hh = planes[0].shape[0]
+    hb = (Hh + n - 1) // n
+    row = np.arange(Hh)
+    for k, p in enumerate(planes):
+        p[row] = recv[row // hb, k, row - (row // hb) * hb]
+
+
+def gloo_gather(send):
+    world = dist.get_world_size()
+    t = torch.from_numpy(np.ascontiguousarray(send).view(np.uint8).reshape(-1))
+    out = torch.empty(world * t.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, t)
+    return out.numpy().view(np.uint16).reshape((world,) + send.shape)
+
+
+def capi_frame(osc, ubo, depth, normal, hist_prev, hist_curr, rank, world, y0, y1, iters, sun_band):
+    Hh, Ww = depth.shape
+    for s in range(rank, (Hh + 7) // 8, world):             # vkr_rtao_trace_stripes
+        a, b = s * 8, min(Hh, (s + 1) * 8)
+        hist_curr[a:b] = osc.trace(ubo, depth, hist_prev, a, b)[a:b]
+    capi_unpack_stripes(gloo_gather(capi_pack_stripes(hist_curr, rank, world)), hist_curr, world)    # vkr_rtao_gather_history
+    lo = lambda h: max(0, y0 - h)                   # noqa: E731
+    hi = lambda h: min(Hh, y1 + h)                  # noqa: E731
+    src = hist_curr
+    for i in range(iters):                                  # vkr_rtao_denoise_band
+        halo_out = 2 * ((1 << iters) - (1 << (i + 1)))
+        src = O.atrous(ubo, 1 << i, src, depth, normal, lo(halo_out), hi(halo_out))
+    full = np.full((Hh, Ww), 0x4321, dtype=np.uint16)       # rows of other ranks must arrive through the gather
+    full[y0:y1] = O.upsample(ubo, src, normal)[y0:y1]
+    sun = np.full((Hh, Ww), 0x4321, dtype=np.uint16)
+    sun[y0:y1] = sun_band.view(np.uint16)
+    planes = [full, sun]
+    capi_unpack_bands(gloo_gather(capi_pack_bands(planes, rank, world)), planes, world)               # vkr_gather_bands
+    return full, sun
+
+
 def main():
     out_dir = sys.argv[1]
     schedule = sys.argv[2] if len(sys.argv) > 2 else "bands"
@@ -84,6 +151,15 @@ def main():
         want_hist = ref.hist[ref.last_curr]
         want_sun = osc.shadow_sun(wp, ng, valid, FrameState.sun_dir_to_light(ubo), 0.01, 4).astype(np.float16)
 
+        if schedule == "capi":
+            hist[parity][:] = 0x1234
+            sun_band = osc.shadow_sun(wp[y0:y1], ng[y0:y1], valid[y0:y1], FrameState.sun_dir_to_light(ubo), 0.01, 4).astype(np.float16)
+            full, sun16 = capi_frame(osc, ubo, depth, normal, hist[parity ^ 1], hist[parity], rank, world, y0, y1, ITERS, sun_band)
+            ok &= np.array_equal(hist[parity], want_hist)
+            ok &= np.array_equal(full, want_full)
+            ok &= np.array_equal(sun16, want_sun.view(np.uint16))
+            parity ^= 1
+            continue
         if schedule == "stripes":
             hist[parity][:] = 0x1234                          # rows of other ranks must arrive through the gather
             full = stripe_frame(osc, ubo, depth, normal, hist[parity ^ 1], hist[parity], rank, world, plan, h_send, h_recv,

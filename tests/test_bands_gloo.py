@@ -78,7 +78,7 @@ def test_stripe_plan_roundtrip(H, n):
     assert torch.equal(out, full)
 
 
-@pytest.mark.parametrize("world,schedule", [(2, "bands"), (3, "bands"), (2, "stripes"), (3, "stripes")])
+@pytest.mark.parametrize("world,schedule", [(2, "bands"), (3, "bands"), (2, "stripes"), (3, "stripes"), (2, "capi"), (3, "capi")])
 def test_band_schedule_over_gloo_matches_full_frame(world, schedule, tmp_path, oracle_mod):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                OMP_NUM_THREADS="2")
