@@ -612,10 +612,13 @@ def main():
         # peak = 1024 SIMDs x 2.4 GHz / (calibrated issue cycles per instruction for K1's instruction mix).  The
         # instruction count and the mix are properties of the code + workload, measured once with rocprofv3 --pmc /
         # the ISA census and read from profiles/ (named in `source`); the issue costs come from tools/calib/issue_rates*.
-        cal = {}
+        cal, model_fresh, model_name = {}, None, os.environ.get("VKR_BENCH_MODEL", "r3_k1_valu_model.json")
         try:
-            with open(os.path.join(ROOT, "profiles", "r2_k1_valu_model.json")) as f:
-                cal = json.load(f).get(wl_name, {})
+            with open(os.path.join(ROOT, "profiles", model_name)) as f:
+                model = json.load(f)
+            cal = model.get(wl_name, {})
+            from vulkanrenderer_amd.fingerprint import kernel_source_fingerprint
+            model_fresh = model.get("source_fingerprint") == kernel_source_fingerprint()
         except Exception:
             cal = {}
         # SURVEY 8(d)'s byte figure (8 B/px + 64 B per node visit + 48 B per triangle test): bytes served by L1/L2, NOT HBM
@@ -644,12 +647,15 @@ def main():
                          "traffic": traffic, "traffic_frac_of_hbm_peak": traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "td_busy_frac": cal.get("td_busy_frac"), "ta_busy_frac": cal.get("ta_busy_frac"),
                          "l1_hit_rate": cal.get("l1_hit_rate"), "l2_hit_rate": cal.get("l2_hit_rate"),
-                         "source": "profiles/r2_k1_valu_model.json <- " + str(cal.get("source")),
+                         "source": f"profiles/{model_name} <- " + str(cal.get("source")),
+                         "model_fresh": model_fresh,
                          "note": "achieved/peak/frac: VALU issue, co-binding with the L1 return path (td_busy_frac), DESIGN.md 4.  peak prices the "
                                  "instruction classes no counter resolves at the fast class, so frac is a lower bound of the issue utilisation; "
                                  "frac_estimate prices them by the static mix of the queue loop.  Instructions per ray, mix, traffic, TA/TD busy "
                                  "and hit rates were measured with rocprofv3 --pmc on this workload (file in `source`), not by this run; launch_ms "
-                                 "and the ray count are this run's.  cache_side_bytes is SURVEY 8(d)'s figure: bytes served by L1/L2, not HBM."})
+                                 "and the ray count are this run's.  model_fresh: the kernel sources in the tree are the ones the counters were "
+                                 "measured on (false = re-profile with tools/refresh_r3.sh; the fractions then describe an older kernel).  "
+                                 "cache_side_bytes is SURVEY 8(d)'s figure: bytes served by L1/L2, not HBM."})
         else:
             roof.update({"bound": "hbm", "achieved": compulsory / (trace_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": compulsory / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -663,7 +669,7 @@ def main():
                               "traffic": (cal["k2_hbm_bytes_per_iteration"] * iters) if cal else None,
                               "launch_ms": atrous_ms, "algorithmic_bytes": atrous_bytes,
                               "valu_insts": (cal["k2_valu_insts_per_iteration"] * iters) if cal else None,
-                              "source": ("profiles/r2_k1_valu_model.json <- " + str(cal.get("source"))) if cal else None,
+                              "source": (f"profiles/{model_name} <- " + str(cal.get("source"))) if cal else None,
                               "note": "VALU-bound by contract: two software exp (bit-exact against the oracle) + pow32 per tap, ~57 "
                                       "instructions x 25 taps per pixel; the v_exp_f32 build (VKR_ATROUS=tol, outside the contract) is timed in DESIGN.md"}
         out["kernels"] = {"trace_ms": trace_ms, "atrous_total_ms": atrous_ms, "upsample_ms": float(np.mean(t_up)),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Build profiles/r2_k1_valu_model.json (what bench.py's `roofline` objects read) from the evidence files of
+"""Build profiles/<round>_k1_valu_model.json (round = VKR_ROUND, default r3) (what bench.py's `roofline` objects read) from the evidence files of
 tools/profile_round2.sh.  usage: make_valu_model.py <tag>:<workload> [<tag>:<workload> ...]
-reads  profiles/<tag>_pmc_summary.txt, profiles/<tag>_bench.json, profiles/r2_k1_isa_census.json,
+reads  profiles/<tag>_pmc_summary.txt, profiles/<tag>_bench.json, profiles/<round>_k1_isa_census.json,
        profiles/r2_issue_rates.jsonl + r2_issue_rates2.jsonl (calibrated issue cycles per opcode)
 
 VALU issue bound of k_trace_q.  The SQ counters give the dynamic number of VALU wave-instructions and a split into
@@ -19,6 +19,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
+ROUND = os.environ.get("VKR_ROUND", "r3")
+sys.path.insert(0, ROOT)
+from vulkanrenderer_amd.fingerprint import kernel_source_fingerprint   # noqa: E402
 FAST, SLOW, TRANS = 2.6, 4.25, 8.24          # cycles per wave-instruction per SIMD (r2_issue_rates*.jsonl, class means)
 
 
@@ -35,7 +38,7 @@ def summary(path):
 
 
 def main():
-    census = json.load(open(os.path.join(P, "r2_k1_isa_census.json")))
+    census = json.load(open(os.path.join(P, f"{ROUND}_k1_isa_census.json")))
     # static class mix of the loop's opcodes that no SQ_INSTS_VALU_* class counter resolves
     ops = census["loop"]["top_valu_opcodes_all"]
     resolved = re.compile(r"v_(add|sub|subrev|mul|fma|fmac|mul_legacy|pk_add|pk_mul|pk_fma)_f32|v_cvt|v_(rcp|rsq|sqrt|exp|log|sin|cos)")
@@ -43,7 +46,10 @@ def main():
     un_cost = sum(n * {"fast": FAST, "slow": SLOW, "trans": TRANS}[census["loop"]["op_class"][o]] for o, n in un.items()) / sum(un.values())
     model = {"_doc": __doc__.strip().split("\n\n")[1].replace("\n", " "),
              "class_cycles": {"fast": FAST, "slow": SLOW, "trans": TRANS, "source": "profiles/r2_issue_rates.jsonl, profiles/r2_issue_rates2.jsonl"},
-             "unresolved_opcodes_static_cost": round(un_cost, 3), "census": "profiles/r2_k1_isa_census.json"}
+             "unresolved_opcodes_static_cost": round(un_cost, 3), "census": f"profiles/{ROUND}_k1_isa_census.json",
+             "source_fingerprint": kernel_source_fingerprint(),
+             "source_fingerprint_note": "sha256 over the kernel sources these counters were measured on (vulkanrenderer_amd/fingerprint.py); bench.py and "
+                                        "tests/test_host_logic.py compare it with the sources in the tree, so a kernel change without a re-profile is reported, not replayed"}
     for arg in sys.argv[1:]:
         tag, wl = arg.split(":")
         s = summary(os.path.join(P, f"{tag}_pmc_summary.txt"))
@@ -84,7 +90,7 @@ def main():
                            "factor 1.69 = 30 B/px) + WRITE_SIZE x1024",
             "k2_valu_insts_per_iteration": k2["SQ_INSTS_VALU"], "k2_iterations": iters,
         }
-    json.dump(model, open(os.path.join(P, "r2_k1_valu_model.json"), "w"), indent=1)
+    json.dump(model, open(os.path.join(P, f"{ROUND}_k1_valu_model.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in model.items() if k in ("c3", "c4")}, indent=1))
 
 

@@ -1397,6 +1397,22 @@ static hipError_t validate_binary_tree(vkr_ctx* c, hipStream_t st)
     return hipSuccess;
 }
 
+// Instance of every triangle of the final order (inst_first_tri[i] <= flat id < inst_first_tri[i + 1]): looked up once per
+// build here instead of once per pixel per frame by the G-buffer producer (a refit keeps order and membership).
+__global__ __launch_bounds__(256) void k_tri_instance(const float4* tris, uint32_t n, const uint32_t* inst_first_tri, uint32_t instance_count,
+                                                      uint32_t* tri_inst)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t flat = f2u(tris[(size_t)i * 3 + 2].w);
+    uint32_t lo = 0, hi = instance_count;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (inst_first_tri[mid] <= flat) lo = mid; else hi = mid;
+    }
+    tri_inst[i] = lo;
+}
+
 // Stage 1 of a build (everything up to the binary fit); the host reads back the binary height, then stage 2
 // collapses to wide nodes.  refit_only: stage 1 re-transforms + refits, stage 2 regathers wide boxes.
 hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
@@ -1446,6 +1462,14 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
                 k_sah_bin<<<(n + SAH_CHUNK - 1) / SAH_CHUNK, 256, 0, st>>>(n, tnode, box, nodes[level & 1], level_count + level, bins);
                 k_sah_split<<<(uint32_t)((cap + 63) / 64), 64, 0, st>>>(nodes[level & 1], nodes[(level + 1) & 1], bins, level_count + level, level);
                 k_sah_assign<<<nb, 256, 0, st>>>(n, tnode, box, path, depth, nodes[level & 1], level_count + level);
+                // every fourth level the host looks at the number of ranges the next level opens and stops launching once there
+                // is none (the scene decides: 16 levels for the bistro-class one, not SAH_DEPTH = 32)
+                if ((level & 3) == 3 && level + 1 < SAH_DEPTH) {
+                    uint32_t open_next = 1u;
+                    VKR_TRY(hipMemcpyAsync(&open_next, level_count + level + 1, 4, hipMemcpyDeviceToHost, st));
+                    VKR_TRY(hipStreamSynchronize(st));
+                    if (open_next == 0u) break;
+                }
             }
             k_sah_rekey<<<nb, 256, 0, st>>>(n, c->d_keys[cur].p, path, depth, key_bits);
             for (int shift = 32; shift < 64; shift += 8) {                     // stable: the Morton order survives inside equal paths
@@ -1475,6 +1499,8 @@ hipError_t bvh_build_launch(vkr_ctx* c, bool refit_only, hipStream_t st)
     if (!refit_only)   // the triangle order is final here; a refit keeps it
         k_alpha_records<<<nb, 256, 0, st>>>(c->d_tris.p, n, c->d_lut.p, c->d_indices.p, c->d_uvs.p, c->d_material_params.p,
                                               c->d_alpha_tex.p, c->d_tri_alpha.p);
+    if (!refit_only)   // ... and so is the instance every triangle came from (the G-buffer producer's normal matrix)
+        k_tri_instance<<<nb, 256, 0, st>>>(c->d_tris.p, n, c->d_inst_first_tri.p, c->instance_count, c->d_tri_inst.p);
     if (!refit_only && c->validate_tree) VKR_TRY(validate_binary_tree(c, st));
     if (n == 1) {
         k_single<<<1, 64, 0, st>>>(c->d_tris.p, c->d_nodes.p, c->d_wide_bref.p, c->d_height.p, (WideCtl*)c->d_wide_ctl.p,
@@ -1516,6 +1542,14 @@ hipError_t bvh_wide_launch(vkr_ctx* c, uint32_t bin_height, hipStream_t st)
                                                                         c->d_wide_bref.p, c->d_wide_bin.p, c->d_bounds.p);
         k_wide_next<<<1, 64, 0, st>>>(ctl);
         if (cap < (uint64_t)n) cap *= 4;
+        // the binary height only bounds the number of levels (39 for the bistro-class scene, whose wide tree has 18): every
+        // eighth level the host reads the control block and stops once the next level is empty
+        if ((level & 7u) == 7u && level + 1u < bin_height + 1u) {
+            uint32_t h[4] = {0, 0, 1, 0};                              // count, level_begin, level_end, levels
+            VKR_TRY(hipMemcpyAsync(h, c->d_wide_ctl.p, 16, hipMemcpyDeviceToHost, st));
+            VKR_TRY(hipStreamSynchronize(st));
+            if (h[1] == h[2]) break;
+        }
     }
     return hipGetLastError();
 }

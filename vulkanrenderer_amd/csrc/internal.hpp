@@ -141,6 +141,7 @@ struct vkr_ctx {
     vkr::DevBuf<float4> d_tris;              // 3 x float4 per leaf, Morton order
     vkr::DevBuf<float4> d_tri_alpha;         // 3 x float4 per triangle (MASK ones written): UVs, cutoff and texture descriptor for the alpha test
     vkr::DevBuf<uint32_t> d_perm;            // sorted position -> flat triangle id
+    vkr::DevBuf<uint32_t> d_tri_inst;        // sorted position -> instance the triangle came from (G-buffer producer)
     vkr::DevBuf<uint32_t> d_leaf_parent, d_node_parent, d_flags;
     vkr::DevBuf<uint64_t> d_keys[2];
     vkr::DevBuf<uint32_t> d_vals[2];
@@ -161,6 +162,7 @@ struct vkr_ctx {
     vkr::DevBuf<uint32_t> d_sun_counter;     // K4 packet form: chunk counter of its persistent waves (separate from K1's)
     bool sun_packets = true;                 // K4 form: one packet per pixel (k_shadow_sun_pkt) or one item per ray (k_shadow_q)
     int atrous_mode = 1;                     // K2 form: 1 LDS-tiled (default), 0 per-pixel gathers (VKR_ATROUS=gather), 2 tiled + v_exp_f32 (VKR_ATROUS=tol, outside the bit-exact contract)
+    bool gbuffer_packets = true;             // G-buffer producer: one packet walk per 8x8 tile (default) or one walk per lane (VKR_GBUFFER_MODE=lane)
     bool trace_streaming = true;             // K1 form: wave-wide queues (k_trace_q) or one ray per lane (k_trace)
     int num_cus = 0;
     int k1_per_cu[2][3] = {{0, 0, 0}, {0, 0, 0}};   // resident k_trace_q workgroups per CU, [STATS][RB - 6]; 0 = not asked yet
@@ -174,7 +176,11 @@ struct vkr_ctx {
     uint32_t cut_l2_begin = 0, cut_l2_count = 0;   // third level of the wide tree, when k_tile_cut may start there (vkr_bvh_build)
     uint32_t cut_max = 16;                   // entries per cut at most (VKR_CUT_MAX, <= K1_CUT_MAX)
     float cut_small = 1.0f;                  // a node joins the cut once its half area is <= this x the half area of the tile's ray bound (VKR_CUT_SMALL)
-    vkr::DevBuf<float4> d_nz;                // per-frame decoded normal.xyz + clamped depth (A-Trous operand)
+    vkr::DevBuf<float4> d_nz;                // decoded normal.xyz + clamped depth: operand plane of the gather form of A-Trous (VKR_ATROUS=gather) only
+    const uint16_t* at_depth = nullptr;      // the frame's A-Trous operands as the caller handed them over (rtao_prep_launch) ...
+    const uint16_t* at_normal = nullptr;
+    int at_y0 = 0, at_y1 = 0;                // ... the rows they are needed on, and whether d_nz holds them yet
+    bool at_nz_valid = false;
     uint32_t frame_parity = 0;               // FrameManager currentFrame % 2
     uint32_t last_curr = 0;
 
@@ -206,6 +212,10 @@ inline SceneDev scene_dev(const vkr_ctx* c)
     s.alpha_tex = c->d_alpha_tex.p;
     s.alpha_data = c->d_alpha_data.p;
     s.tri_alpha = c->d_tri_alpha.p;
+    s.tri_inst = c->d_tri_inst.p;
+#ifdef VKR_PKT_STATS
+    s.pkt_stats = c->d_stats.p;
+#endif
     s.normals = c->d_normals.p;
     s.mesh_has_normals = c->d_mesh_has_normals.p;
     s.inst_first_tri = c->d_inst_first_tri.p;

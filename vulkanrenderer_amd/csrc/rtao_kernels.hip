@@ -626,13 +626,6 @@ __host__ __device__ inline int q_item_pixels(int rb, int rayCount)
     return p;
 }
 
-// v_max3 / v_min3 / v_max / v_min as they are: __builtin_fmaxf makes hipcc quiet its operands first (v_max x, x), eight
-// extra instructions per node step.  The slab values are never signalling NaNs.
-VKR_DI float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-VKR_DI float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-VKR_DI float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-VKR_DI float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-
 // -DVKR_DEBUG_BOUNDS: every LDS queue / ray / global-stack index of k_trace_q is checked on the device; a violation sets a bit
 // in stats[23] (read back by vkr_trace_stats_get under VKR_PHASE_DUMP) and the index is forced to 0, so the run stays in
 // bounds and reports instead of faulting.  (Round 1 recorded an undiagnosed GPU fault of a 7-waves-per-SIMD build.)
@@ -1679,12 +1672,15 @@ __global__ __launch_bounds__(256) void k_prep(const uint16_t* depth, const uint1
     nz[o] = make_float4(r.x, r.y, r.z, z);
 }
 
+// The frame's A-Trous operands.  The tiled kernel (the default) decodes them itself while it stages a tile, so nothing is launched
+// here; the gather form reads the float4 plane, which is written on its first use in the frame (rtao_atrous_launch).
 hipError_t rtao_prep_launch(vkr_ctx* c, const uint16_t* depth, const uint16_t* normal, int y0, int y1, hipStream_t st)
 {
-    if (y1 <= y0) return hipSuccess;
-    dim3 grid((c->W + 63u) / 64u, ((uint32_t)(y1 - y0) + 3u) / 4u);
-    k_prep<<<grid, 256, 0, st>>>(depth, normal, c->d_nz.p, (int)c->W, y0, y1);
-    return hipGetLastError();
+    (void)st;
+    c->at_depth = depth; c->at_normal = normal;
+    c->at_y0 = y0; c->at_y1 = y1;
+    c->at_nz_valid = false;
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1747,7 +1743,10 @@ __global__ __launch_bounds__(256) void k_atrous(const uint16_t* src, const float
 // exp's final scaling by 2^k is v_ldexp_f32, which rounds exactly like the multiplication by the float 2^k.
 // TOL (build/ env switch, NOT the default): range and depth weights through v_exp_f32 -- outside the bit-exact contract,
 // measured against the oracle in DESIGN.md.
-constexpr int AT_TX = 32, AT_TY = 8, AT_LW = AT_TX + 4, AT_LH = AT_TY + 4;
+#ifndef AT_ROWS
+#define AT_ROWS 8         // rows of a tile: 8 (one pixel per thread, 36x12 staged texels for 256 outputs: 1.69x) or 16 (two per thread, 1.41x: measured slower, 0.285 vs 0.273 ms)
+#endif
+constexpr int AT_TX = 32, AT_TY = AT_ROWS, AT_LW = AT_TX + 4, AT_LH = AT_TY + 4;
 
 VKR_DI float det_exp_ld(float x)   // det_exp with v_ldexp_f32 for the last step (same bits: both forms round once)
 {
@@ -1765,7 +1764,7 @@ VKR_DI float det_exp_ld(float x)   // det_exp with v_ldexp_f32 for the last step
 }
 
 template <bool TOL>
-__global__ __launch_bounds__(256) void k_atrous_tile(const uint16_t* src, const float4* nz, uint16_t* dst, uint16_t* dst2,
+__global__ __launch_bounds__(256) void k_atrous_tile(const uint16_t* src, const uint16_t* depth, const uint16_t* normal, uint16_t* dst, uint16_t* dst2,
                                                      int W, int H, int y0, int y1, int step, float sigmaAbs)
 {
     __shared__ float4 s_nz[AT_LH][AT_LW];
@@ -1778,12 +1777,20 @@ __global__ __launch_bounds__(256) void k_atrous_tile(const uint16_t* src, const 
         const int gy = iclamp(y0 + sb + step * (j0 + ly - 2), 0, H - 1);
         const size_t to = (size_t)gy * W + gx;
         s_ao[ly][lx] = half_to_float(src[to]);                                      // :82-89
-        s_nz[ly][lx] = nz[to];                                                      // :92-94
+        // decodeNormalSafe (:38-46) + max(depth, 1e-3) (:70-71,92-93) once per staged texel, straight from the R16F / RGBA16F
+        // inputs (12 B per texel instead of an 18-B pre-decoded operand plane and the launch that wrote it); k_prep's arithmetic
+        const ushort4 e = ((const ushort4*)normal)[to];
+        const V3 n = V3{half_to_float(e.x) * 2.0f - 1.0f, half_to_float(e.y) * 2.0f - 1.0f, half_to_float(e.z) * 2.0f - 1.0f};
+        const float l2 = dot3(n, n);
+        // 1 / sqrt: rcp_ieee is the correctly rounded quotient where the select below keeps it (l2 >= 1e-6), traverse.hpp
+        const V3 r = (n.x != n.x || n.y != n.y || n.z != n.z || l2 < 1e-6f) ? v3(0, 1, 0) : n * rcp_ieee(sqrt_(l2));
+        s_nz[ly][lx] = make_float4(r.x, r.y, r.z, gmax(half_to_float(depth[to]), 1e-3f));   // :92-94
     }
     __syncthreads();
-    const int tx = (int)threadIdx.x & (AT_TX - 1), ty = (int)threadIdx.x >> 5;
+    for (int part = 0; part < AT_TY / 8; ++part) {                                  // 256 threads, AT_TY / 8 pixels each
+    const int tx = (int)threadIdx.x & (AT_TX - 1), ty = ((int)threadIdx.x >> 5) + 8 * part;
     const int px = sa + step * (i0 + tx), py = y0 + sb + step * (j0 + ty);
-    if (px >= W || py >= y1) return;
+    if (px >= W || py >= y1) continue;
     const float center = s_ao[ty + 2][tx + 2];                                      // :62-69
     const float4 cn = s_nz[ty + 2][tx + 2];                                         // :70-72
     const float centerZ = cn.w;
@@ -1822,6 +1829,7 @@ __global__ __launch_bounds__(256) void k_atrous_tile(const uint16_t* src, const 
     const uint16_t r = float_to_half(filtered);
     dst[o] = r;                                                                     // :115-119
     if (dst2) dst2[o] = r;
+    }
 }
 
 hipError_t rtao_atrous_launch(vkr_ctx* c, float radius_raw, int step, const uint16_t* src, uint16_t* dst,
@@ -1832,7 +1840,13 @@ hipError_t rtao_atrous_launch(vkr_ctx* c, float radius_raw, int step, const uint
     if (!(radius_raw == radius_raw)) radius = radius_raw;                       // GLSL max(NaN, y) = NaN
     float sigmaAbs = (0.01f < radius * 0.05f) ? radius * 0.05f : 0.01f;         // :101
     if (step < 1) step = 1;                                                     // :76
+    if (!c->at_depth || !c->at_normal) return hipErrorInvalidValue;             // rtao_prep_launch names the frame's operands first
     if (c->atrous_mode == 0 || step > 64) {                                     // VKR_ATROUS=gather: one thread per pixel, 25 global gathers
+        if (!c->at_nz_valid) {                                                  // its pre-decoded operand plane, once per frame
+            dim3 pg((c->W + 63u) / 64u, ((uint32_t)(c->at_y1 - c->at_y0) + 3u) / 4u);
+            k_prep<<<pg, 256, 0, st>>>(c->at_depth, c->at_normal, c->d_nz.p, (int)c->W, c->at_y0, c->at_y1);
+            c->at_nz_valid = true;
+        }
         dim3 grid((c->W + 31u) / 32u, ((uint32_t)(y1 - y0) + 7u) / 8u);
         k_atrous<<<grid, 256, 0, st>>>(src, c->d_nz.p, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
         return hipGetLastError();
@@ -1841,9 +1855,9 @@ hipError_t rtao_atrous_launch(vkr_ctx* c, float radius_raw, int step, const uint
     const uint32_t sh = ((uint32_t)(y1 - y0) + (uint32_t)step - 1u) / (uint32_t)step;
     dim3 grid((sw + AT_TX - 1u) / AT_TX, (sh + AT_TY - 1u) / AT_TY, (uint32_t)(step * step));
     if (c->atrous_mode == 2)
-        k_atrous_tile<true><<<grid, 256, 0, st>>>(src, c->d_nz.p, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
+        k_atrous_tile<true><<<grid, 256, 0, st>>>(src, c->at_depth, c->at_normal, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
     else
-        k_atrous_tile<false><<<grid, 256, 0, st>>>(src, c->d_nz.p, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
+        k_atrous_tile<false><<<grid, 256, 0, st>>>(src, c->at_depth, c->at_normal, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
     return hipGetLastError();
 }
 

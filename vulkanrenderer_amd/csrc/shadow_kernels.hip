@@ -102,17 +102,22 @@ VKR_DI V3 world_normal(const float* N, V3 n)
 // Primary visibility: what DepthPrepass leaves in linearDepthResolve / normalResolve
 // (depth_prepass.vert:42-52 viewZ = -viewPos.z; depth_only.frag:31-34 normal*0.5+0.5, linear Z), plus the
 // worldPos / Ng varyings pbr.frag shades with (:339-346).
+// PKT: the 64 primary rays of a wave's 8x8 tile walk the tree as one packet (traverse_packet, traverse.hpp) -- they share
+// their origin and nearly their path, so the node fetches, the stack and the control flow are paid once per tile instead of
+// once per ray; per ray the result is the per-lane walk's, bit for bit.  !PKT (VKR_GBUFFER_MODE=lane): one walk per lane.
+template <bool PKT>
 __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer(SceneDev sc, FrameParams fp, uint16_t* depth,
                                                              uint16_t* normal, float* wpOut, float* ngOut,
                                                              uint8_t* validOut, uint32_t tiles_x)
 {
-    __shared__ uint32_t s_stack[2 * VKR_LDS_STACK * VKR_TRACE_BLOCK];
-    uint32_t* stack = s_stack + threadIdx.x;
+    __shared__ uint32_t s_stack[PKT ? (VKR_TRACE_BLOCK / 64) * VKR_MAX_STACK : 2 * VKR_LDS_STACK * VKR_TRACE_BLOCK];
+    uint32_t* stack = PKT ? s_stack + (threadIdx.x >> 6) * VKR_MAX_STACK : s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = (int)(blockIdx.x % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
     const int y = (int)(blockIdx.x / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int W = fp.W, H = fp.H;
-    if (x >= W || y >= H) return;
+    const bool inside = !(x >= W || y >= H);
+    if (!PKT && !inside) return;                               // a packet needs all 64 lanes: outside lanes cast no ray
     size_t o = (size_t)y * W + x;
     float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
     float fv[4];
@@ -121,7 +126,10 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer(SceneDev sc, FrameP
     V3 d = normalize3(mul_m3_v3(fp.invView, dv));
     V3 cam = V3{fp.camPos[0], fp.camPos[1], fp.camPos[2]};
     HitDev h;
-    bool hit = traverse<Q_PRIMARY, false>(sc, cam, d, 0.0f, 1.0e30f, &h, stack, nullptr);
+    bool hit;
+    if (PKT) hit = traverse_packet<Q_PRIMARY>(sc, cam, d, inside, 0.0f, 1.0e30f, &h, stack);
+    else hit = traverse<Q_PRIMARY, false>(sc, cam, d, 0.0f, 1.0e30f, &h, stack, nullptr);
+    if (!inside) return;
     float z = 0.0f;
     V3 n = v3(0, 0, 1), wp = v3(0, 0, 0), ng = v3(0, 1, 0);
     if (hit) {
@@ -136,11 +144,8 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer(SceneDev sc, FrameP
         const uint32_t mesh = f2u(a.w) & 0x0fffffffu, prim = f2u(b.w), flat = f2u(c.w);
         if (sc.mesh_has_normals[mesh]) {
             // depth_prepass.vert:47-48 per vertex, rasteriser interpolation, depth_only.frag:31
-            uint32_t lo = 0, hi = sc.instance_count;       // instance with inst_first_tri[i] <= flat < inst_first_tri[i+1]
-            while (hi - lo > 1u) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (sc.inst_first_tri[mid] <= flat) lo = mid; else hi = mid;
-            }
+            const uint32_t lo = sc.tri_inst[h.tri];        // instance with inst_first_tri[i] <= flat < inst_first_tri[i+1] (k_tri_instance)
+            (void)flat;
             float N[9];
             normal_matrix(sc.inst_xf + 12 * (size_t)lo, N);
             const uint32_t ioff = sc.lut[mesh].y + 3u * prim;
@@ -198,15 +203,17 @@ VKR_DI V3 primary_dir(const FrameParams& fp, float fx, float fy)
     return normalize3(mul_m3_v3(fp.invView, dv));
 }
 
+template <bool PKT>
 __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer_msaa(SceneDev sc, FrameParams fp, int set, uint16_t* depth,
                                                                   uint16_t* normal, uint8_t* validOut, uint32_t tiles_x)
 {
-    __shared__ uint32_t s_stack[2 * VKR_LDS_STACK * VKR_TRACE_BLOCK];
-    uint32_t* stack = s_stack + threadIdx.x;
+    __shared__ uint32_t s_stack[PKT ? (VKR_TRACE_BLOCK / 64) * VKR_MAX_STACK : 2 * VKR_LDS_STACK * VKR_TRACE_BLOCK];
+    uint32_t* stack = PKT ? s_stack + (threadIdx.x >> 6) * VKR_MAX_STACK : s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = (int)(blockIdx.x % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
     const int y = (int)(blockIdx.x / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (x >= fp.W || y >= fp.H) return;
+    const bool inside = !(x >= fp.W || y >= fp.H);
+    if (!PKT && !inside) return;                               // a packet needs all 64 lanes: outside lanes cast no ray
     const size_t o = (size_t)y * fp.W + x;
     const int S = 1 << set;
     const V3 cam = V3{fp.camPos[0], fp.camPos[1], fp.camPos[2]};
@@ -216,7 +223,9 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer_msaa(SceneDev sc, F
         const V3 ds = primary_dir(fp, (float)x + c_sample_pos[set][k][0], (float)y + c_sample_pos[set][k][1]);
         HitDev h;
         uint16_t zh = 0, e0 = float_to_half(0.5f), e1h = float_to_half(0.5f), e2h = float_to_half(1.0f), e3 = float_to_half(1.0f);
-        if (traverse<Q_PRIMARY_MS, false>(sc, cam, ds, 0.0f, 1.0e30f, &h, stack, nullptr, dc)) {
+        const bool got = PKT ? traverse_packet<Q_PRIMARY_MS>(sc, cam, ds, inside, 0.0f, 1.0e30f, &h, stack, dc)
+                             : traverse<Q_PRIMARY_MS, false>(sc, cam, ds, 0.0f, 1.0e30f, &h, stack, nullptr, dc);
+        if (got) {
             const float4* tp = sc.tris + (size_t)h.tri * 3;
             const float4 a = tp[0], b = tp[1], c = tp[2];
             const V3 v0 = V3{a.x, a.y, a.z}, e1 = V3{b.x, b.y, b.z}, e2 = V3{c.x, c.y, c.z};
@@ -240,11 +249,8 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer_msaa(SceneDev sc, F
             V3 n = normalize3(cross3(e1, e2));
             const uint32_t mesh = f2u(a.w) & 0x0fffffffu, prim = f2u(b.w), flat = f2u(c.w);
             if (sc.mesh_has_normals[mesh]) {
-                uint32_t lo = 0, hi = sc.instance_count;
-                while (hi - lo > 1u) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (sc.inst_first_tri[mid] <= flat) lo = mid; else hi = mid;
-                }
+                const uint32_t lo = sc.tri_inst[h.tri];
+                (void)flat;
                 float N[9];
                 normal_matrix(sc.inst_xf + 12 * (size_t)lo, N);
                 const uint32_t ioff = sc.lut[mesh].y + 3u * prim;
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(VKR_TRACE_BLOCK) void k_gbuffer_msaa(SceneDev sc, F
         zsum = zsum + half_to_float(zh);
         n0 = n0 + half_to_float(e0); n1 = n1 + half_to_float(e1h); n2 = n2 + half_to_float(e2h); n3 = n3 + half_to_float(e3);
     }
+    if (!inside) return;
     const float invS = 1.0f / (float)S;
     const uint16_t zr = float_to_half(zsum * invS);
     if (depth) depth[o] = zr;
@@ -1040,7 +1047,8 @@ hipError_t gbuffer_launch(vkr_ctx* c, const FrameParams& fp, uint16_t* depth, ui
                           uint8_t* valid, hipStream_t st)
 {
     uint32_t tiles_x = ((uint32_t)fp.W + 15u) / 16u, tiles_y = ((uint32_t)fp.H + 15u) / 16u;
-    k_gbuffer<<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, depth, normal, wp, ng, valid, tiles_x);
+    if (c->gbuffer_packets) k_gbuffer<true><<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, depth, normal, wp, ng, valid, tiles_x);
+    else k_gbuffer<false><<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, depth, normal, wp, ng, valid, tiles_x);
     return hipGetLastError();
 }
 
@@ -1050,10 +1058,16 @@ hipError_t gbuffer_msaa_launch(vkr_ctx* c, const FrameParams& fp, int samples, u
     const int set = samples == 8 ? 3 : (samples == 4 ? 2 : (samples == 2 ? 1 : 0));
     uint32_t tiles_x = ((uint32_t)fp.W + 15u) / 16u, tiles_y = ((uint32_t)fp.H + 15u) / 16u;
     // pixel-centre outputs (and, for one sample, everything) from the one-sample kernel
-    k_gbuffer<<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, set == 0 ? depth : nullptr, set == 0 ? normal : nullptr,
-                                                             wp, ng, set == 0 ? valid : nullptr, tiles_x);
-    if (set != 0)
-        k_gbuffer_msaa<<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, set, depth, normal, valid, tiles_x);
+    if (c->gbuffer_packets)
+        k_gbuffer<true><<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, set == 0 ? depth : nullptr, set == 0 ? normal : nullptr,
+                                                                       wp, ng, set == 0 ? valid : nullptr, tiles_x);
+    else
+        k_gbuffer<false><<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, set == 0 ? depth : nullptr, set == 0 ? normal : nullptr,
+                                                                        wp, ng, set == 0 ? valid : nullptr, tiles_x);
+    if (set != 0) {
+        if (c->gbuffer_packets) k_gbuffer_msaa<true><<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, set, depth, normal, valid, tiles_x);
+        else k_gbuffer_msaa<false><<<tiles_x * tiles_y, VKR_TRACE_BLOCK, 0, st>>>(scene_dev(c), fp, set, depth, normal, valid, tiles_x);
+    }
     return hipGetLastError();
 }
 

@@ -69,6 +69,10 @@ struct SceneDev {
     const float* normals;            // merged xyz
     const uint32_t* mesh_has_normals;
     const uint32_t* inst_first_tri;  // exclusive prefix of triangles per instance (+1 entry)
+    const uint32_t* tri_inst;        // per triangle (sorted order): its instance
+#ifdef VKR_PKT_STATS
+    unsigned long long* pkt_stats;   // development counters of traverse_packet: packets, node visits, triangle tests
+#endif
     const float* inst_xf;            // 12 floats per instance
     uint32_t instance_count;
 };
@@ -150,11 +154,42 @@ struct NodeDec {
 #define VKR_PRIO_LO
 #endif
 
+// v_max3 / v_min3 / v_max / v_min as they are: __builtin_fmaxf makes hipcc quiet its operands first (v_max x, x), eight
+// extra instructions per node step.  The slab values are never signalling NaNs.
+VKR_DI float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+VKR_DI float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+VKR_DI float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+VKR_DI float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+VKR_DI f2v pk_fma(f2v a, float b, float c) { return __builtin_elementwise_fma(a, f2v{b, b}, f2v{c, c}); }   // v_pk_fma_f32
+
 VKR_DI float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
 
 VKR_DI void decode_node(const float4* np, NodeDec& n)
 {
     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    const float sx = q2.z, sy = q2.w, sz = q0.w;
+    const uint32_t wminx = f2u(q1.x), wminy = f2u(q1.y), wminz = f2u(q1.z), wmaxx = f2u(q1.w), wmaxy = f2u(q2.x),
+                   wmaxz = f2u(q2.y);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        n.mnx[k] = fma_(ubyte_f(wminx, k), sx, q0.x); n.mxx[k] = fma_(ubyte_f(wmaxx, k), sx, q0.x);
+        n.mny[k] = fma_(ubyte_f(wminy, k), sy, q0.y); n.mxy[k] = fma_(ubyte_f(wmaxy, k), sy, q0.y);
+        n.mnz[k] = fma_(ubyte_f(wminz, k), sz, q0.z); n.mxz[k] = fma_(ubyte_f(wmaxz, k), sz, q0.z);
+    }
+    n.ref[0] = f2u(q3.x); n.ref[1] = f2u(q3.y); n.ref[2] = f2u(q3.z); n.ref[3] = f2u(q3.w);
+}
+
+#ifndef VKR_PKT_SCALAR_LOADS
+#define VKR_PKT_SCALAR_LOADS 1   // traverse_packet fetches its (wave-uniform) nodes and triangles with scalar loads
+#endif
+typedef float vkr_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) vkr_f4* vkr_cf4p;   // constant address space: uniform addresses become s_load
+VKR_DI float4 ldk(vkr_cf4p p, int i) { const vkr_f4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+VKR_DI void decode_node_k(vkr_cf4p np, NodeDec& n)                   // decode_node() on a node fetched through it
+{
+    const float4 q0 = ldk(np, 0), q1 = ldk(np, 1), q2 = ldk(np, 2), q3 = ldk(np, 3);
     const float sx = q2.z, sy = q2.w, sz = q0.w;
     const uint32_t wminx = f2u(q1.x), wminy = f2u(q1.y), wminz = f2u(q1.z), wmaxx = f2u(q1.w), wmaxy = f2u(q2.x),
                    wmaxz = f2u(q2.y);
@@ -314,10 +349,6 @@ __device__ __forceinline__ bool traverse(const SceneDev& sc, V3 o, V3 d, float t
     return found;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Shared pieces of the streaming (wave-wide queue) kernels: k_trace_q (rtao_kernels.hip), k_shadow_q
-// (shadow_kernels.hip).
-// ---------------------------------------------------------------------------------------------
 // 1/x for slab tests: approximate reciprocal, magnitude capped so that 0 * inf never appears (a ray parallel to a
 // slab then sees +-1e18-scaled distances, which order exactly like the infinite ones)
 VKR_DI float safe_rcp(float x)
@@ -326,6 +357,159 @@ VKR_DI float safe_rcp(float x)
     float a = __builtin_fminf(__builtin_fabsf(r), 1.0e18f);
     return __builtin_copysignf(a, x);
 }
+// ---------------------------------------------------------------------------------------------
+// Packet form of traverse<Q_PRIMARY / Q_PRIMARY_MS>() for coherent rays (the G-buffer producer: the 64 primary rays of an
+// 8x8 pixel tile).  One wave walks the tree ONCE for its 64 rays: control flow, the node stack (one word per entry, in LDS,
+// `wstack` = this wave's VKR_MAX_STACK words) and every node / triangle address are wave-uniform, each lane tests the
+// fetched boxes and triangles against its own ray.  A child is opened when any lane's ray enters its box in front of that
+// lane's closest hit; siblings are opened in the order of the entry distance of the first lane that hits them.  Per lane the
+// triangle test, the candidate filter and the tie-break are those of traverse<>(), and the closest hit does not depend on the
+// visiting order, so every lane's result is bit-identical to the per-lane walk.  `alive` = false: the lane casts no ray (it
+// still has to take part: all 64 lanes of the wave must call this).
+template <int MODE>
+__device__ __forceinline__ bool traverse_packet(const SceneDev& sc, V3 o, V3 d, bool alive, float tmin, float tmax, HitDev* hit,
+                                                uint32_t* wstack, V3 dc = V3{0.0f, 0.0f, 1.0f})
+{
+    static_assert(MODE == Q_PRIMARY || MODE == Q_PRIMARY_MS, "packets serve the primary rays");
+    float tbest = alive ? tmax : -1.0f;                       // nothing lies inside (tmin, -1)
+    uint32_t best_flat = 0xffffffffu, best_tri = 0xffffffffu;
+    float bu = 0.0f, bv = 0.0f;
+    bool found = false;
+    if (sc.tri_count == 0) return false;
+    const V3 id = V3{safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z)};   // capped: the fused slab test must never see 0 * inf
+    int sp = 0;
+    uint32_t cur = 0;                                          // root
+#ifdef VKR_PKT_STATS
+    uint32_t st_nodes = 0, st_tris = 0, st_lane_tris = 0;
+#endif
+    for (;;) {
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        bool pop = false;
+        if ((int)cur >= 0) {
+#ifdef VKR_PKT_STATS
+            st_nodes++;
+#endif
+            // Slab tests in the fused form of the streaming kernels (plane distance = fma(byte, scale / d, (origin - o) / d), near / far
+            // byte quads picked by the direction sign), with the relative padding of box_key() because these rays are long.  The
+            // address is wave-uniform and the tree is read-only while this kernel runs: through the constant address space the 64
+            // bytes arrive as scalar loads (scalar cache, no trip through the vector memory path).
+#if VKR_PKT_SCALAR_LOADS
+            vkr_cf4p np = (vkr_cf4p)(sc.nodes + (size_t)cur * 4);
+            const float4 q0 = ldk(np, 0), q1 = ldk(np, 1), q2 = ldk(np, 2), q3 = ldk(np, 3);
+#else
+            const float4* np = sc.nodes + (size_t)cur * 4;
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+#endif
+            const float tb = tbest * 1.000001f;
+            const float ax = q2.z * id.x, ay = q2.w * id.y, az = q0.w * id.z;
+            const float bx = (q0.x - o.x) * id.x, by = (q0.y - o.y) * id.y, bz = (q0.z - o.z) * id.z;
+            const uint32_t nx4 = id.x >= 0.0f ? f2u(q1.x) : f2u(q1.w), fx4 = id.x >= 0.0f ? f2u(q1.w) : f2u(q1.x);
+            const uint32_t ny4 = id.y >= 0.0f ? f2u(q1.y) : f2u(q2.x), fy4 = id.y >= 0.0f ? f2u(q2.x) : f2u(q1.y);
+            const uint32_t nz4 = id.z >= 0.0f ? f2u(q1.z) : f2u(q2.y), fz4 = id.z >= 0.0f ? f2u(q2.y) : f2u(q1.z);
+            const uint32_t ref[4] = {f2u(q3.x), f2u(q3.y), f2u(q3.z), f2u(q3.w)};
+#define VKR_PLANES(W, A, B, P01, P23)                                                                               \
+    const f2v P01 = pk_fma(f2v{ubyte_f(W, 0), ubyte_f(W, 1)}, A, B), P23 = pk_fma(f2v{ubyte_f(W, 2), ubyte_f(W, 3)}, A, B);
+            VKR_PLANES(nx4, ax, bx, nx01, nx23) VKR_PLANES(ny4, ay, by, ny01, ny23) VKR_PLANES(nz4, az, bz, nz01, nz23)
+            VKR_PLANES(fx4, ax, bx, fx01, fx23) VKR_PLANES(fy4, ay, by, fy01, fy23) VKR_PLANES(fz4, az, bz, fz01, fz23)
+#undef VKR_PLANES
+            // key: entry distance bits (>= tmin >= 0: they order like unsigned integers) with the slot in the two low bits
+#define VKR_SLABK(K, SLOT, NX, NY, NZ, FX, FY, FZ)                                                                  \
+    uint32_t K;                                                                                                     \
+    {                                                                                                               \
+        float tn = vmax3(NX, NY, NZ), tf = vmin3(FX, FY, FZ);                                                       \
+        tn = vmax2(tn - __builtin_fabsf(tn) * 1e-6f, tmin);                                                         \
+        tf = vmin2(tf + __builtin_fabsf(tf) * 1e-6f, tb);                                                           \
+        K = (tn <= tf && ref[SLOT] != VKR_CHILD_NONE) ? ((f2u(tn) & ~3u) | (uint32_t)(SLOT)) : 0xffffffffu;         \
+    }
+            VKR_SLABK(k0, 0, nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x)
+            VKR_SLABK(k1, 1, nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y)
+            VKR_SLABK(k2, 2, nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x)
+            VKR_SLABK(k3, 3, nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y)
+#undef VKR_SLABK
+            // per child: the key of the first lane that hits it (wave-uniform; 0xffffffff when no lane does)
+            auto first_key = [&](uint32_t k) -> uint32_t {
+                const unsigned long long m = __ballot(k != 0xffffffffu);
+                if (m == 0ull) return 0xffffffffu;
+                return (uint32_t)__builtin_amdgcn_readlane((int)k, (int)(__ffsll((long long)m) - 1));
+            };
+            uint32_t u0 = first_key(k0), u1 = first_key(k1), u2 = first_key(k2), u3 = first_key(k3);
+            cswap(u0, u1); cswap(u2, u3); cswap(u0, u2); cswap(u1, u3); cswap(u1, u2);  // ascending
+            auto ref_of = [&](uint32_t key) -> uint32_t {
+                const uint32_t sl = key & 3u;
+                return sl == 0u ? ref[0] : (sl == 1u ? ref[1] : (sl == 2u ? ref[2] : ref[3]));
+            };
+            if (u0 == 0xffffffffu) pop = true;
+            else {
+                if (u3 != 0xffffffffu) wstack[sp++] = ref_of(u3);
+                if (u2 != 0xffffffffu) wstack[sp++] = ref_of(u2);
+                if (u1 != 0xffffffffu) wstack[sp++] = ref_of(u1);
+                cur = ref_of(u0);
+            }
+        } else {
+            const uint32_t first = leaf_ref_first(cur), count = leaf_ref_count(cur);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t ti = first + k;
+#ifdef VKR_PKT_STATS
+                st_tris++;
+#endif
+#if VKR_PKT_SCALAR_LOADS
+                vkr_cf4p tp = (vkr_cf4p)(sc.tris + (size_t)ti * 3);
+                const float4 a = ldk(tp, 0), b = ldk(tp, 1), c = ldk(tp, 2);
+#else
+                const float4* tp = sc.tris + (size_t)ti * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+#endif
+                const V3 v0 = V3{a.x, a.y, a.z}, e1 = V3{b.x, b.y, b.z}, e2 = V3{c.x, c.y, c.z};
+                const V3 pvec = cross3(d, e2);
+                const float det = dot3(e1, pvec);
+                if (det == 0.0f) continue;
+                const float inv = 1.0f / det;
+                const V3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * inv;
+                if (!(u >= 0.0f && u <= 1.0f)) continue;
+                const V3 qvec = cross3(tvec, e1);
+                const float v = dot3(d, qvec) * inv;
+                if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+                const float t = dot3(e2, qvec) * inv;
+                if (!(t > tmin)) continue;
+                const uint32_t flat = f2u(c.w);
+                if (!(t < tbest || (t == tbest && flat < best_flat))) continue;
+                const uint32_t mw = f2u(a.w);
+                const uint32_t cls = mw >> 28;
+                if (cls == 1u) continue;
+                if (cls == 2u) {
+                    float au = u, av = v;
+                    if (MODE == Q_PRIMARY_MS) {
+                        const V3 pc = cross3(dc, e2);
+                        const float detc = dot3(e1, pc);
+                        if (detc == 0.0f) continue;           // plane edge-on to the centre ray: no fragment value exists
+                        const float invc = 1.0f / detc;
+                        au = dot3(tvec, pc) * invc;
+                        av = dot3(dc, qvec) * invc;
+                    }
+                    if (!alpha_test(sc, mw & 0x0fffffffu, f2u(b.w), au, av)) continue;
+                }
+                tbest = t; best_flat = flat; best_tri = ti; bu = u; bv = v; found = true;
+            }
+            pop = true;
+        }
+        if (pop) {
+            if (sp == 0) break;
+            cur = wstack[--sp];
+        }
+    }
+#ifdef VKR_PKT_STATS
+    if ((threadIdx.x & 63u) == 0u && sc.pkt_stats) { atomicAdd(&sc.pkt_stats[0], 1ull); atomicAdd(&sc.pkt_stats[1], (unsigned long long)st_nodes); atomicAdd(&sc.pkt_stats[2], (unsigned long long)st_tris); }
+    (void)st_lane_tris;
+#endif
+    if (hit) { hit->t = tbest; hit->tri = best_tri; hit->u = bu; hit->v = bv; }
+    return found;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared pieces of the streaming (wave-wide queue) kernels: k_trace_q (rtao_kernels.hip), k_shadow_q
+// (shadow_kernels.hip).
+// ---------------------------------------------------------------------------------------------
 #ifndef KQ_NQ
 #define KQ_NQ 1024         // node queue capacity in LDS: 4-byte items, ray << 22 | wide node index
 #endif
@@ -353,9 +537,6 @@ VKR_DI uint32_t wave_incl_scan(uint32_t x)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return (uint32_t)v;
 }
-
-typedef float f2v __attribute__((ext_vector_type(2)));
-VKR_DI f2v pk_fma(f2v a, float b, float c) { return __builtin_elementwise_fma(a, f2v{b, b}, f2v{c, c}); }   // v_pk_fma_f32
 
 // Moeller-Trumbore exactly as in k_trace / traverse<>() (operation order is part of the numeric contract): no culling,
 // t strictly inside (tmin, tbest).

@@ -130,6 +130,7 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     if (const char* e = getenv("VKR_CUT_SMALL")) { float v = (float)atof(e); if (v > 0.0f) c->cut_small = v; }
     if (const char* e = getenv("VKR_ATROUS")) c->atrous_mode = !strcmp(e, "gather") ? 0 : (!strcmp(e, "tol") ? 2 : 1);
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
+    if (const char* e = getenv("VKR_GBUFFER_MODE")) c->gbuffer_packets = (e[0] != 'l');  // "lane" = one walk per lane
     if (const char* e = getenv("VKR_SUN_MODE")) c->sun_packets = (e[0] != 'r');         // "ray" = one queue item per ray
     (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     c->H = desc->height;
@@ -164,7 +165,7 @@ void vkr_destroy(vkr_ctx* c)
     c->d_positions.release(); c->d_indices.release(); c->d_uvs.release(); c->d_lut.release();
     c->d_mesh_class.release(); c->d_material_params.release(); c->d_alpha_tex.release(); c->d_alpha_data.release();
     c->d_inst_mesh.release(); c->d_inst_first_tri.release(); c->d_inst_xf.release();
-    c->d_nodes.release(); c->d_tris.release(); c->d_tri_alpha.release(); c->d_perm.release(); c->d_leaf_parent.release();
+    c->d_nodes.release(); c->d_tris.release(); c->d_tri_alpha.release(); c->d_perm.release(); c->d_tri_inst.release(); c->d_leaf_parent.release();
     c->d_node_parent.release(); c->d_flags.release();
     c->d_bin_child.release(); c->d_bin_range.release(); c->d_deposit.release(); c->d_node_box.release();
     c->d_wide_ctl.release(); c->d_wide_bin.release(); c->d_wide_bref.release();
@@ -330,6 +331,7 @@ int vkr_scene_upload(vkr_ctx* c, const vkr_scene_desc* s)
     HIP_OR_FAIL(c, c->d_tris.alloc(n * 3));
     HIP_OR_FAIL(c, c->d_tri_alpha.alloc(n * 3));
     HIP_OR_FAIL(c, c->d_perm.alloc(n));
+    HIP_OR_FAIL(c, c->d_tri_inst.alloc(n));
     HIP_OR_FAIL(c, c->d_leaf_parent.alloc(n));
     HIP_OR_FAIL(c, c->d_node_parent.alloc(n));
     HIP_OR_FAIL(c, c->d_flags.alloc(n));
@@ -785,7 +787,8 @@ int vkr_rtao_atrous(vkr_ctx* c, const vkr_rtao_frame_io* io, uint32_t step, uint
     // rtao_atrous.comp:57-69: dst = iter&1 ; src = iter==0 ? historyCurr : ping[(iter-1)&1]
     const uint16_t* src = (iteration == 0) ? c->d_hist_img[c->frame_parity].p : c->d_ping[(iteration - 1u) & 1u].p;
     uint16_t* dst = c->d_ping[iteration & 1u].p;
-    if (iteration == 0) HIP_OR_FAIL(c, rtao_prep_launch(c, io->linear_depth_r16f, io->normal_rgba16f, 0, (int)c->H, st));
+    if (iteration == 0 || c->at_depth != io->linear_depth_r16f || c->at_normal != io->normal_rgba16f)
+        HIP_OR_FAIL(c, rtao_prep_launch(c, io->linear_depth_r16f, io->normal_rgba16f, 0, (int)c->H, st));
     HIP_OR_FAIL(c, rtao_atrous_launch(c, io->ubo[VKR_UBO_RTAO_PARAMS0 + 2], (int)(step > 0x40000000u ? 0x40000000u : step),
                                       src, dst, nullptr, 0, (int)c->H, st));
     return VKR_OK;
