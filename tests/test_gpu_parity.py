@@ -285,6 +285,18 @@ def test_all_sky_and_empty_scene(torch_mod, oracle_mod):
     ref = O.OracleRtaoPass(oe, W, H, 2).execute(ubo, depth, normal)
     assert np.array_equal(ref, to_np_u16(rpass.rtao_full))
     rt.updateTopLevelAS(empty.instance_mesh, empty.instance_transform)     # refit of nothing is a no-op
+    # rays straight through the root's origin along (1, 1, 1): the three axis crossings coincide there, the one case in which
+    # inverted planes alone would not make the empty root's slots miss (the kernels never walk a tree of zero triangles)
+    import torch
+    wp = torch.zeros((H, W, 3), dtype=torch.float32, device=ctx.device)
+    wp[:] = torch.tensor([-2.0, -2.0, -2.0])
+    gb.world_pos.copy_(wp)
+    gb.geom_normal.zero_()
+    gb.valid.fill_(1)
+    u2 = ubo.copy()
+    u2[48:51] = (-1.0, -1.0, -1.0)                                         # directionalLightDir: L = normalize(1, 1, 1)
+    u2[60:63] = (2.0, 2.0, 2.0)                                            # light 0 on the same diagonal
+    assert float(sh.sun(u2).min().item()) == 1.0 and float(sh.point(u2, 0).min().item()) == 1.0
     ctx.close()
 
 

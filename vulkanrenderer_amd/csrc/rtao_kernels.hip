@@ -537,20 +537,20 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 // (ballot + mbcnt compaction; a leaf reference becomes a leaf item with one add); a leaf step tests the leaf's
 // triangles and lowers the ray's closest hit with an LDS atomic min on the float bits; MASK candidates queue up
 // once more and are alpha-tested a wave at a time.  No ordering, no per-lane stack: the closest committed hit does
-// not depend on the order triangles are met in.  The self-hit retry (:193-200) is a second round over the rays that
-// need it.
+// not depend on the order triangles are met in.  The self-hit retry (:193-200) re-traces a ray on the spot (K1_EARLY_RETRY).
 //
-// Round-2 shape ("fat waves"): 3 waves per SIMD instead of 6, each with twice the work in flight --
-//   * a node step pops up to 128 items, two per lane, and issues both node fetches before the first slab test;
-//   * the ray records the node step needs ({origin | tMin}, {1/direction | closest hit}) live in LDS (8 KB per wave)
-//     instead of a 24 KB global slice per wave that the 6144 resident waves kept evicting from L2 (0.9 GB written and
-//     2.5 GB fetched per frame in round 1); only the direction (leaf steps) stays in global memory;
-//   * <= 168 VGPRs: nothing spills (round 1: 80 VGPRs, 26 spilled, 116 SGPRs spilled into VGPR lanes);
-//   * queue overflow goes to a small global stack per wave instead of sizing the LDS queues for the worst case, and
-//     the step width is throttled only when LDS + global capacity could run out (strict depth-first bound).
+// Shipped shape:
+//   * 6 waves per SIMD (80 VGPRs; what spills sits in the rare refill / alpha paths, not in the node or leaf step), one item
+//     per lane per step (K1_STEP 64), items of 2^7 = 128 rays (K1_RB 7: 16 pixels x 8 rays);
+//   * the ray records the node step needs ({origin | tMin}, {1/direction | closest hit}) live in LDS (32 B per ray); only the
+//     direction (leaf steps) stays in the wave's global slice;
+//   * LDS queues of 288 node + 128 leaf + 128 alpha entries; overflow goes to a small global stack per wave, and the step
+//     width is throttled only when LDS + global capacity could run out (strict depth-first bound);
+//   * the per-pixel head and tail of main() run as kernels of their own (K1_SPLIT: k_pix_setup, k_pix_resolve);
+//   * rays enter the tree at the cut of their 8x8 tile (K1_CUT: k_tile_cut), not at the root.
 // ---------------------------------------------------------------------------------------------
 #ifndef K1_WAVES
-#define K1_WAVES 6         // resident waves per SIMD the kernel is compiled for (VGPR budget 512 / K1_WAVES: 80, 2 spilled in the alpha path)
+#define K1_WAVES 6         // resident waves per SIMD the kernel is compiled for (VGPR budget 512 / K1_WAVES: 80)
 #endif
 #ifndef K1_RB
 #define K1_RB 7            // ray bits of an item at most: 2^K1_RB rays (32 B of LDS each)
@@ -1483,8 +1483,8 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     }
 }
 
-// ray bits of the streaming kernel for this tree: 8 (256 rays per item) while triangle and node indices fit the item
-// payload, fewer for larger trees; 0 = the tree needs the one-ray-per-lane kernel
+// ray bits of the streaming kernel for this tree: K1_RB = 7 (128 rays per item) while triangle and node indices fit the item
+// payload of 32 - RB bits, 6 for larger trees; 0 = the tree needs the one-ray-per-lane kernel
 static int q_ray_bits(const vkr_ctx* c)
 {
     for (int rb = K1_RB; rb >= 6; --rb)

@@ -517,7 +517,8 @@ __device__ __forceinline__ bool traverse_packet(const SceneDev& sc, V3 o, V3 d, 
 #define KQ_LQ 320          // leaf queue capacity in LDS: a node step runs with < 64 leaves queued and adds <= 256
 #endif
 constexpr int KQ_AQ = 128;               // alpha-test queue: drained whenever it holds a full wave of candidates
-constexpr uint32_t KQ_NODE_BITS = 22;    // the host falls back to k_trace for trees of more than 2^22 wide nodes
+constexpr uint32_t KQ_NODE_BITS = 22;    // item payload of the shadow kernels (k_shadow_q, k_shadow_sun_pkt): trees of more than 2^22 wide nodes take
+                                         // their one-ray-per-lane forms (K1 sizes its own payload: q_ray_bits, rtao_kernels.hip)
 constexpr uint32_t KQ_GUARD = 3u * 32u;   // head-room for strict depth-first growth: 3 deferred children per level, <= 32 levels
 
 VKR_DI uint32_t mbcnt64(unsigned long long m)
