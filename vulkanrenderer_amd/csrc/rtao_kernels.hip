@@ -102,7 +102,15 @@ VKR_DI bool computePrevUv(const float* prevViewProj, V3 worldPos, V2* prevUv)  /
 // ---------------------------------------------------------------------------------------------
 constexpr int CUR_DONE = -1;   // not a leaf reference: it would name triangle 2^30 - 1 (the scene limit is 2^28)
 
-constexpr int K1_BLOCK = 64;
+#ifndef K1_WG
+#define K1_WG 4            // waves per k_trace_q workgroup: 1, or 4 = the waves of a workgroup take neighbouring items at the same time (below)
+#endif
+constexpr int K1_BLOCK = 64;                 // k_trace (one ray per lane)
+constexpr int K1Q_BLOCK = 64 * K1_WG;        // k_trace_q
+#ifndef K1_UNIT_TILES
+#define K1_UNIT_TILES 1    // K1_WG > 1: 8x8 tiles a workgroup fetches from the counters at a time
+#endif
+constexpr uint32_t K1_RING = 16;             // K1_WG > 1: units a workgroup keeps published at a time
 
 VKR_DI uint32_t ray_slice_float4s(int rayCount) { return (uint32_t)rayCount * 64u * 2u + (uint32_t)rayCount * 16u; }
 
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(64) void k_tile_cut(SceneDev sc, uint32_t n_tiles, 
 struct NodeIn { float4 a, b, q0, q1, q2, q3; uint32_t rayhi; };   // one popped node item with its operands in flight
 
 template <bool STATS, int RB>
-__global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k_trace_q(
+__global__ __launch_bounds__(K1Q_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k_trace_q(
     SceneDev sc, FrameParams fp, const uint16_t* depthP, const uint16_t* histPrevP, uint16_t* histCurr, uint32_t* hitMask,
     int y0, int y1, uint32_t tiles_x, uint32_t n_items, float4* rayBuf, uint32_t* tile_counter, unsigned long long* stats,
     const float4* pixctx, float2* visOut, const uint4* cuts)
@@ -826,7 +834,9 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     constexpr uint32_t RAYS = 1u << RB;
     constexpr uint32_t SH = 32u - (uint32_t)RB;              // item = ray << SH | payload
     constexpr uint32_t PMASK = (1u << SH) - 1u;
-    extern __shared__ float4 smem4[];
+    extern __shared__ float4 smem_all[];
+    const uint32_t wave_in_wg = K1_WG > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+    float4* smem4 = smem_all + wave_in_wg * (uint32_t)(q_lds_bytes(RB) / 16u);     // this wave's part of the workgroup's LDS
     float4* s_ra = smem4;                                     // [RAYS] origin.xyz | tMin        (round 1: advanced origin | tMin')
     float4* s_rb = smem4 + RAYS;                              // [RAYS] 1/direction | closest hit so far (float bits)
 #if K1_DIR_LDS
@@ -843,12 +853,12 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     (void)s_cut;
 
     const int rayCount = fp.rayCount;                         // :252
-    const int lane = threadIdx.x;
+    const int lane = K1_WG > 1 ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : (int)threadIdx.x;
     const int W = fp.W, H = fp.H;
     const Img16 depth{depthP, W, H}, histPrev{histPrevP, W, H};
     (void)depth; (void)histPrev;
     const QSliceLayout lay = q_slice_layout(RB);
-    float4* g_dir = rayBuf + (size_t)blockIdx.x * lay.total_f4;          // [RAYS] direction | tMin as generated
+    float4* g_dir = rayBuf + ((size_t)blockIdx.x * K1_WG + wave_in_wg) * lay.total_f4;          // [RAYS] direction | tMin as generated
     uint32_t* retry_list = (uint32_t*)(g_dir + lay.dir_f4);
     uint32_t* g_nq = (uint32_t*)(g_dir + lay.dir_f4 + lay.retry_f4);
     uint32_t* g_lq = g_nq + K1_GNQ;
@@ -872,14 +882,68 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
     // the next slab when that one is drained, so the waves that share an L2 work on neighbouring pixels (speed only: any
     // wave may take any item).
     uint32_t slab = 0, slabs_done = 0;
+    (void)slabs_done;
     if (K1_SLABS > 1) {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         slab = (xcc & 0xfu) % (uint32_t)K1_SLABS;
     }
     const uint32_t item_rows = n_items / tiles_x;             // rows of items in the launch
+#if K1_WG > 1
+    // K1_WG waves per workgroup: the counters hand out UNITS of K1_WG consecutive items in tile-major order (the items of a
+    // tile follow each other, then the next tile of the row), and the waves of a workgroup -- which share a CU, and with it
+    // the L1 -- take the items of one unit at the same time: their rays start centimetres apart and walk the same nodes and
+    // triangles, so what one wave pulled into L1 the others find there.  No barrier: a wave takes the next free (unit, slot)
+    // of its workgroup from an LDS counter; the wave that gets slot 0 fetches the unit from the slab counters and publishes
+    // it in a small LDS ring, the others wait for that entry (the publisher is resident and running: the wait is bounded).
+    // A ring entry is reused K1_RING units later; its publisher first waits until the K1_WG readers of the previous use have
+    // counted themselves in (they do so a few instructions after taking their slot, before any tracing).
+    uint32_t* s_take = (uint32_t*)(smem_all + (uint32_t)K1_WG * (uint32_t)(q_lds_bytes(RB) / 16u));   // [0] taken, [4 + 4j] tag, unit, readers so far
+    if (threadIdx.x < 4u + 4u * K1_RING) s_take[threadIdx.x] = (threadIdx.x >= 4u && (threadIdx.x & 3u) == 0u) ? 0xffffffffu : 0u;
+    __syncthreads();
+    const uint32_t home_slab = slab;
+    const uint32_t unit_items = (items_per_block > (uint32_t)K1_WG ? items_per_block : (uint32_t)K1_WG) * (uint32_t)K1_UNIT_TILES;
+#endif
     for (;;) {
         uint32_t item = 0;
+#if K1_WG > 1
+        VKR_PRIO_HI      // the counter's round trip and the pixel records' loads come next
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&s_take[0], 1u);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        const uint32_t j = k / unit_items, wslot = k % unit_items, ring = 4u + 4u * (j % K1_RING);
+        uint32_t unit = 0xfffffffeu;                            // slab << 28 | unit of that slab; 0xfffffffe = nothing left
+        if (wslot == 0u) {
+            if (lane == 0) {
+                for (uint32_t t = 0; t < (uint32_t)K1_SLABS; ++t) {           // home slab first; drained counters only grow
+                    const uint32_t sl = (home_slab + t) % (uint32_t)K1_SLABS;
+                    const uint32_t sc0 = sl * tiles_x / (uint32_t)K1_SLABS, sc1 = (sl + 1u) * tiles_x / (uint32_t)K1_SLABS;
+                    const uint32_t u = atomicAdd(tile_counter + sl * 16u, 1u);
+                    if ((unsigned long long)u * unit_items < (unsigned long long)(sc1 - sc0) * item_rows) { unit = (sl << 28) | u; break; }
+                }
+                while (__hip_atomic_load(&s_take[ring + 2u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (j / K1_RING) * unit_items)
+                    __builtin_amdgcn_s_sleep(1);
+                __hip_atomic_store(&s_take[ring + 1u], unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_take[ring], j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (lane == 0) {
+            while (__hip_atomic_load(&s_take[ring], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j) __builtin_amdgcn_s_sleep(1);
+            unit = __hip_atomic_load(&s_take[ring + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_take[ring + 2u], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+        if (unit == 0xfffffffeu) break;                         // every counter is drained: every later unit of this workgroup says so too
+        slab = unit >> 28;
+        const uint32_t c0 = slab * tiles_x / (uint32_t)K1_SLABS, c1 = (slab + 1u) * tiles_x / (uint32_t)K1_SLABS;
+        const uint32_t slab_items = (c1 - c0) * item_rows;
+        item = (unit & 0x0fffffffu) * unit_items + wslot;
+        if (item >= slab_items) continue;                       // the slab's last unit may be short
+        VKR_STAMP(7)
+        // tile-major: item = (row of tiles * tiles of the slab + tile) * items per tile + item of the tile
+        const uint32_t sub = item % items_per_block, tl = item / items_per_block;
+        const uint32_t tile_x = c0 + tl % (c1 - c0), trow = tl / (c1 - c0);
+#else
         const uint32_t c0 = slab * tiles_x / (uint32_t)K1_SLABS, c1 = (slab + 1u) * tiles_x / (uint32_t)K1_SLABS;
         const uint32_t slab_items = (c1 - c0) * item_rows;
         VKR_PRIO_HI      // the counter's round trip and the pixel records' loads come next
@@ -894,6 +958,7 @@ __global__ __launch_bounds__(K1_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WAV
         const uint32_t r_ = item / (c1 - c0);                                 // row of items: 8-row stripe * sub-block
         const uint32_t tile_x = c0 + item % (c1 - c0);
         const uint32_t sub = r_ % items_per_block, trow = r_ / items_per_block;
+#endif
         const uint32_t idx = sub * (uint32_t)P + (uint32_t)plane;             // pixel of the 8x8 block, row-major
         const int px = (int)tile_x * 8 + (int)(idx & 7u);
         const int py = y0 + (int)trow * 8 * fp.stripeMul + (int)(idx >> 3);
@@ -1502,17 +1567,17 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     hipError_t e;
     const uint32_t n_items = tiles_x * tiles_y * (64u / (uint32_t)q_item_pixels(RB, fp.rayCount));
     // persistent waves: as many blocks as the GPU holds at once, each with its own scratch slice (grow-only)
-    const size_t lds = q_lds_bytes(RB) + (size_t)c->k1_extra_lds;            // VKR_K1_EXTRA_LDS: occupancy experiments (development)
+    const size_t lds = q_lds_bytes(RB) * K1_WG + (K1_WG > 1 ? (4u + 4u * K1_RING) * 4u : 0u) + (size_t)c->k1_extra_lds;   // VKR_K1_EXTRA_LDS: occupancy experiments (development)
     // resident workgroups per CU: asked of the runtime once per kernel instance and context, not per frame (a frame makes no
     // host query, allocation or synchronisation once its buffers exist: vkr_rtao_execute can be captured into a HIP graph)
     int& per_cu = c->k1_per_cu[STATS ? 1 : 0][RB - 6];
     if (per_cu == 0) {
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<STATS, RB>, K1_BLOCK, lds)) != hipSuccess) { per_cu = 0; return e; }
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<STATS, RB>, K1Q_BLOCK, lds)) != hipSuccess) { per_cu = 0; return e; }
         if (per_cu < 1) per_cu = 1;
     }
     uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
-    if (blocks > n_items) blocks = n_items;
-    const size_t need = (size_t)blocks * q_slice_layout(RB).total_f4;
+    if (blocks > (n_items + K1_WG - 1u) / K1_WG) blocks = (n_items + K1_WG - 1u) / K1_WG;
+    const size_t need = (size_t)blocks * K1_WG * q_slice_layout(RB).total_f4;
     if (c->d_raybuf.n < need) {
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
         if ((e = c->d_raybuf.alloc(need)) != hipSuccess) return e;
@@ -1548,7 +1613,7 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     }
 #endif
 #endif
-    k_trace_q<STATS, RB><<<blocks, K1_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, n_items,
+    k_trace_q<STATS, RB><<<blocks, K1Q_BLOCK, lds, st>>>(sc, fp, depth, hist_prev, hist_curr, hit_mask, y0, y1, tiles_x, n_items,
                                                         c->d_raybuf.p, c->d_tile_counter.p,
 #ifdef VKR_DEBUG_BOUNDS
                                                         c->d_stats.p
@@ -1570,21 +1635,21 @@ hipError_t rtao_prepare(vkr_ctx* c, hipStream_t st)
     const int rb = c->trace_streaming ? q_ray_bits(c) : 0;
     if (rb == 0) return hipSuccess;
     hipError_t e;
-    const size_t lds = q_lds_bytes(rb) + (size_t)c->k1_extra_lds;
+    const size_t lds = q_lds_bytes(rb) * K1_WG + (K1_WG > 1 ? (4u + 4u * K1_RING) * 4u : 0u) + (size_t)c->k1_extra_lds;
     int& per_cu = c->k1_per_cu[0][rb - 6];
     if (per_cu == 0) {
 #if K1_RB >= 8
-        if (rb == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 8>, K1_BLOCK, lds); else
+        if (rb == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 8>, K1Q_BLOCK, lds); else
 #endif
 #if K1_RB >= 7
-        if (rb == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 7>, K1_BLOCK, lds); else
+        if (rb == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 7>, K1Q_BLOCK, lds); else
 #endif
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 6>, K1_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_q<false, 6>, K1Q_BLOCK, lds);
         if (e != hipSuccess) { per_cu = 0; return e; }
         if (per_cu < 1) per_cu = 1;
     }
     const size_t blocks = (size_t)per_cu * (size_t)(c->num_cus > 0 ? c->num_cus : 256);
-    const size_t need = blocks * q_slice_layout(rb).total_f4;
+    const size_t need = blocks * K1_WG * q_slice_layout(rb).total_f4;
     const size_t npx = (size_t)c->W * c->H;
     const size_t tiles = (size_t)((c->W + 7u) / 8u) * ((c->H + 7u) / 8u + 1u);     // a band that starts between tile rows has one row more
     constexpr uint32_t n_ctr = 16u * (K1_SLABS > 8 ? K1_SLABS : 8);
