@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build profiles/<round>_k1_valu_model.json (round = VKR_ROUND, default r3) (what bench.py's `roofline` objects read) from the evidence files of
-tools/profile_round2.sh.  usage: make_valu_model.py <tag>:<workload> [<tag>:<workload> ...]
+tools/profile_round3.sh.  usage: make_valu_model.py <tag>:<workload> [<tag>:<workload> ...]
 reads  profiles/<tag>_pmc_summary.txt, profiles/<tag>_bench.json, profiles/<round>_k1_isa_census.json,
        profiles/r2_issue_rates.jsonl + r2_issue_rates2.jsonl (calibrated issue cycles per opcode)
 
@@ -44,6 +44,10 @@ def main():
     resolved = re.compile(r"v_(add|sub|subrev|mul|fma|fmac|mul_legacy|pk_add|pk_mul|pk_fma)_f32|v_cvt|v_(rcp|rsq|sqrt|exp|log|sin|cos)")
     un = {o: n for o, n in ops.items() if not resolved.match(o)}
     un_cost = sum(n * {"fast": FAST, "slow": SLOW, "trans": TRANS}[census["loop"]["op_class"][o]] for o, n in un.items()) / sum(un.values())
+    # K2 (k_atrous_tile) has no inner loop worth isolating: the whole kernel's static mix prices its unresolved instructions
+    census2 = json.load(open(os.path.join(P, f"{ROUND}_k2_isa_census.json")))["whole_kernel"]
+    un2 = {o: n for o, n in census2["top_valu_opcodes_all"].items() if not resolved.match(o)}
+    un2_cost = sum(n * {"fast": FAST, "slow": SLOW, "trans": TRANS}[census2["op_class"][o]] for o, n in un2.items()) / sum(un2.values())
     model = {"_doc": __doc__.strip().split("\n\n")[1].replace("\n", " "),
              "class_cycles": {"fast": FAST, "slow": SLOW, "trans": TRANS, "source": "profiles/r2_issue_rates.jsonl, profiles/r2_issue_rates2.jsonl"},
              "unresolved_opcodes_static_cost": round(un_cost, 3), "census": f"profiles/{ROUND}_k1_isa_census.json",
@@ -65,6 +69,12 @@ def main():
         cu_cycles = k1["GRBM_GUI_ACTIVE"] / 8.0 * 256.0          # GRBM_GUI_ACTIVE sums the 8 XCDs; TA/TD/TCP *_sum sum the 256 CUs
         ao_rays = bench["kernels"]["ao_mrays_per_s_kernel"] * 1e3 * bench["kernels"]["trace_ms"]      # AO + retry rays of one K1 launch
         iters = 4
+        wh = re.search(r" (\d+)x(\d+),", bench["config"]["workload"])          # AO resolution of the profiled run
+        k2n = k2["SQ_INSTS_VALU"]
+        k2_fast = k2["SQ_INSTS_VALU_ADD_F32"] + k2["SQ_INSTS_VALU_MUL_F32"] + k2["SQ_INSTS_VALU_FMA_F32"]
+        k2_un = k2n - k2_fast - k2["SQ_INSTS_VALU_TRANS_F32"] - k2["SQ_INSTS_VALU_CVT"]
+        k2_lower = (k2_fast * FAST + k2["SQ_INSTS_VALU_TRANS_F32"] * TRANS + k2["SQ_INSTS_VALU_CVT"] * SLOW + k2_un * FAST) / k2n
+        k2_est = (k2_fast * FAST + k2["SQ_INSTS_VALU_TRANS_F32"] * TRANS + k2["SQ_INSTS_VALU_CVT"] * SLOW + k2_un * un2_cost) / k2n
         model[wl] = {
             "kernel": next(k for k in s if "k_trace_q<false" in k),
             "source": f"profiles/{tag}_pmc_summary.txt (rocprofv3 --pmc, one counter group per run, mean over the dispatches of a 4-frame bench run); "
@@ -86,9 +96,14 @@ def main():
             "l2_hit_rate": k1["TCC_HIT_sum"] / (k1["TCC_HIT_sum"] + k1["TCC_MISS_sum"]),
             "wave_cycles_issue_stalled_frac": k1["SQ_WAIT_INST_ANY"] / k1["SQ_WAVE_CYCLES"],
             "k2_hbm_bytes_per_iteration": k2["FETCH_SIZE"] * 1024.0 + k2["WRITE_SIZE"] * 1024.0,
-            "k2_hbm_note": "k_atrous_tile: FETCH_SIZE x1024 uncorrected (matches the kernel's own read volume: (16 B nz + 2 B ao) x (36x12)/(32x8) halo "
-                           "factor 1.69 = 30 B/px) + WRITE_SIZE x1024",
+            "k2_hbm_note": "k_atrous_tile: FETCH_SIZE x1024 uncorrected (the kernel's own read volume: (8 B normal + 2 B depth + 2 B ao) x (36x12)/(32x8) "
+                           "halo factor 1.69 = 20 B/px) + WRITE_SIZE x1024",
             "k2_valu_insts_per_iteration": k2["SQ_INSTS_VALU"], "k2_iterations": iters,
+            "k2_pixels": int(wh.group(1)) * int(wh.group(2)),
+            "k2_mean_issue_cycles_lower": round(k2_lower, 3), "k2_mean_issue_cycles_estimate": round(k2_est, 3),
+            "k2_valu_mix": {"f32_add_mul_fma (fast)": k2_fast / k2n, "trans": k2["SQ_INSTS_VALU_TRANS_F32"] / k2n, "cvt (slow)": k2["SQ_INSTS_VALU_CVT"] / k2n,
+                            "int32 + rest (unresolved)": k2_un / k2n},
+            "k2_census": f"profiles/{ROUND}_k2_isa_census.json", "k2_unresolved_opcodes_static_cost": round(un2_cost, 3),
         }
     json.dump(model, open(os.path.join(P, f"{ROUND}_k1_valu_model.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in model.items() if k in ("c3", "c4")}, indent=1))

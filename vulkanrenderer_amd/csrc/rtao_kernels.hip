@@ -1830,12 +1830,22 @@ VKR_DI float det_exp_ld(float x)   // det_exp with v_ldexp_f32 for the last step
 
 template <bool TOL>
 __global__ __launch_bounds__(256) void k_atrous_tile(const uint16_t* src, const uint16_t* depth, const uint16_t* normal, uint16_t* dst, uint16_t* dst2,
-                                                     int W, int H, int y0, int y1, int step, float sigmaAbs)
+                                                     int W, int H, int y0, int y1, int step, float sigmaAbs,
+                                                     uint32_t tiles_x, uint32_t tiles_y, uint32_t per_xcd)
 {
     __shared__ float4 s_nz[AT_LH][AT_LW];
     __shared__ float s_ao[AT_LH][AT_LW];
-    const int sub = (int)blockIdx.z, sa = sub % step, sb = sub / step;            // sub-image (x mod step, row offset in the band)
-    const int i0 = (int)blockIdx.x * AT_TX, j0 = (int)blockIdx.y * AT_TY;          // tile origin in sub-image coordinates
+    // Workgroups go to the 8 XCDs round robin by their linear id, and each XCD has its own L2.  The `step` sub-images with
+    // equal row offset read the same 128-byte lines (a line holds 16 neighbouring normals, a sub-image uses every step-th of
+    // them), so work item w = (x offset fastest, then tile, then row offset) is dealt out in contiguous runs per XCD: the
+    // sub-images that share lines run on one XCD at about the same time and the line comes from HBM once, not `step` times.
+    const uint32_t w = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (w >= tiles_x * tiles_y * (uint32_t)(step * step)) return;                  // the whole workgroup: before any barrier
+    const int sa = (int)(w % (uint32_t)step);                                      // sub-image: x mod step ...
+    uint32_t t_ = w / (uint32_t)step;
+    const int i0 = (int)(t_ % tiles_x) * AT_TX;                                    // tile origin in sub-image coordinates
+    t_ /= tiles_x;
+    const int j0 = (int)(t_ % tiles_y) * AT_TY, sb = (int)(t_ / tiles_y);          // ... and row offset in the band
     for (int t = (int)threadIdx.x; t < AT_LW * AT_LH; t += 256) {
         const int ly = t / AT_LW, lx = t - ly * AT_LW;
         const int gx = iclamp(sa + step * (i0 + lx - 2), 0, W - 1);                // = clamp(px + x*step) of :81 for every tap that reads it
@@ -1918,11 +1928,12 @@ hipError_t rtao_atrous_launch(vkr_ctx* c, float radius_raw, int step, const uint
     }
     const uint32_t sw = ((uint32_t)c->W + (uint32_t)step - 1u) / (uint32_t)step;            // sub-image extent
     const uint32_t sh = ((uint32_t)(y1 - y0) + (uint32_t)step - 1u) / (uint32_t)step;
-    dim3 grid((sw + AT_TX - 1u) / AT_TX, (sh + AT_TY - 1u) / AT_TY, (uint32_t)(step * step));
+    const uint32_t tiles_x = (sw + AT_TX - 1u) / AT_TX, tiles_y = (sh + AT_TY - 1u) / AT_TY;
+    const uint32_t per_xcd = (tiles_x * tiles_y * (uint32_t)(step * step) + 7u) / 8u, grid = per_xcd * 8u;
     if (c->atrous_mode == 2)
-        k_atrous_tile<true><<<grid, 256, 0, st>>>(src, c->at_depth, c->at_normal, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
+        k_atrous_tile<true><<<grid, 256, 0, st>>>(src, c->at_depth, c->at_normal, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs, tiles_x, tiles_y, per_xcd);
     else
-        k_atrous_tile<false><<<grid, 256, 0, st>>>(src, c->at_depth, c->at_normal, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs);
+        k_atrous_tile<false><<<grid, 256, 0, st>>>(src, c->at_depth, c->at_normal, dst, dst2, (int)c->W, (int)c->H, y0, y1, step, sigmaAbs, tiles_x, tiles_y, per_xcd);
     return hipGetLastError();
 }
 
