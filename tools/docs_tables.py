@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""The result tables of DESIGN.md / BASELINE.md / README.md, generated from the evidence files in profiles/.
+
+Every table that quotes measured numbers sits between a pair of markers
+
+    <!-- gen:NAME -->            ...            <!-- /gen:NAME -->
+
+and is the output of the function of that NAME below, which reads nothing but committed files under profiles/
+(bench JSON lines, rocprofv3 kernel statistics, the PMC model).  `tools/docs_tables.py --write` rewrites the blocks in
+place (tools/refresh_r3.sh does it after every re-profile); `tests/test_docs_consistency.py` regenerates them and fails
+when a block's text structure differs from the generator's or any number in it is more than 10 % away from the
+evidence -- so a table cannot keep quoting an older kernel.
+"""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+DOCS = ("DESIGN.md", "BASELINE.md", "README.md")
+ROUND = "r3"
+
+
+def _bench(name):
+    with open(os.path.join(P, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def _stats(name):
+    out = {}
+    with open(os.path.join(P, name)) as f:
+        for r in csv.DictReader(f):
+            key = re.sub(r"^void ", "", r["Name"]).replace("vkr::", "")
+            key = re.match(r"[A-Za-z_0-9]+(<[^>(]*>)?", key).group(0)
+            out[key] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)       # calls, average in microseconds
+    return out
+
+
+def _model():
+    with open(os.path.join(P, f"{ROUND}_k1_valu_model.json")) as f:
+        return json.load(f)
+
+
+def _us(stats, key):
+    return f"{stats[key][1]:.1f}" if key in stats else "n/a"
+
+
+def headline():
+    c3, c4 = _bench(f"{ROUND}_final_bench.json"), _bench(f"{ROUND}_final_c4_bench.json")
+    rows = ["| Workload (`bench.py --workload`) | ms per frame | `value` Mrays/s | K1 trace+temporal ms | A-Trous x4 ms | sun shadows ms | point light ms | BVH build / refit ms |",
+            "|---|---|---|---|---|---|---|---|"]
+    for name, d in (("c3 (default): bistro-class 1920x1080, 8 AO rays/px, 4 A-Trous iterations", c3),
+                    ("c4: 3840x2160, 8 AO + 16 sun rays/px", c4)):
+        k = d["kernels"]
+        sun = f"{k['sun_shadow_ms_full_frame']:.2f}" if "sun_shadow_ms_full_frame" in k else "-"
+        pt = f"{k['point_shadow_ms_full_frame_per_light']:.2f}" if "point_shadow_ms_full_frame_per_light" in k else "-"
+        rows.append(f"| {name} | {d['ms_per_step']:.2f} | {d['value']:.0f} | {k['trace_ms']:.2f} | {k['atrous_total_ms']:.3f} | {sun} | {pt} | "
+                    f"{d['config']['lbvh_build_ms']:.1f} / {k['bvh_refit_ms']:.2f} |")
+    rd3, rd4 = c3["kernels"]["reference_default_8rays_5iters"], c4["kernels"]["reference_default_8rays_5iters"]
+    rows.append("")
+    rows.append(f"Reference default settings (8 rays, 5 A-Trous iterations, steps 1-16) on the same frames: c3 {rd3['frame_ms']:.2f} ms per frame "
+                f"(A-Trous {rd3['atrous_total_ms']:.3f} ms), c4 {rd4['frame_ms']:.2f} ms (A-Trous {rd4['atrous_total_ms']:.3f} ms; AO chain only). "
+                f"Parity inside the bench run: {c3['parity']['mismatching_pixels']} of {c3['parity']['pixels']} `rtao_full` pixels differ from the oracle.")
+    return "\n".join(rows)
+
+
+def kernel_times():
+    s3, s4 = _stats(f"{ROUND}_final_kernel_stats.csv"), _stats(f"{ROUND}_final_c4_kernel_stats.csv")
+    rows = ["| Kernel (rocprofv3 `--kernel-trace --stats`, average per launch) | c3, µs | c4, µs |", "|---|---|---|"]
+    for label, key in (("`k_pix_setup` (per-pixel setup, tile bounds)", "k_pix_setup"), ("`k_tile_cut` (entry cut per 8x8 tile)", "k_tile_cut"),
+                       ("`k_trace_q<false, 7>` (ray generation + traversal)", "k_trace_q<false, 7>"),
+                       ("`k_pix_resolve` (temporal)", "k_pix_resolve"), ("`k_atrous_tile<false>` (one A-Trous iteration)", "k_atrous_tile<false>"),
+                       ("`k_shadow_sun_pkt` (16 sun-disc rays per pixel)", "k_shadow_sun_pkt"), ("`k_shadow_q<1>` (one point light)", "k_shadow_q<1>"),
+                       ("`k_gbuffer<true>` (primary rays, packet form)", "k_gbuffer<true>")):
+        rows.append(f"| {label} | {_us(s3, key)} | {_us(s4, key)} |")
+    rows.append("")
+    rows.append("At c4 the sun kernel runs on a second stream, so the small kernels that queue behind a persistent launch (`k_pix_setup`, `k_pix_resolve`, "
+                "`k_sun_setup`) show their wait for a free wave slot, not their execution time.")
+    return "\n".join(rows)
+
+
+def k1_counters():
+    m, c3, c4 = _model(), _bench(f"{ROUND}_final_bench.json"), _bench(f"{ROUND}_final_c4_bench.json")
+    rows = ["| `k_trace_q`, per launch (rocprofv3 `--pmc`, `profiles/r3_final*_pmc_summary.txt`) | c3 | c4 |", "|---|---|---|"]
+
+    def row(label, f):
+        rows.append(f"| {label} | {f(m['c3'], c3)} | {f(m['c4'], c4)} |")
+    row("node visits / triangle tests per ray", lambda a, b: f"{b['roofline']['nodes_per_ray']:.1f} / {b['roofline']['tris_per_ray']:.1f}")
+    row("lanes carrying an item: node steps / leaf steps", lambda a, b: f"{b['roofline']['lane_util_node_loop']:.2f} / {b['roofline']['lane_util_tri_loop']:.2f}")
+    row("VALU wave-instructions per ray", lambda a, b: f"{a['valu_insts_per_ray']:.1f}")
+    row("VALU / SALU / LDS / vector-load instructions, G per launch",
+        lambda a, b: f"{a['valu_insts_per_launch'] / 1e9:.2f} / {a['salu_insts_per_launch'] / 1e9:.2f} / {a['lds_insts_per_launch'] / 1e9:.3f} / {a['vmem_rd_insts_per_launch'] / 1e9:.3f}")
+    row("issue cycles per VALU instruction: lower bound / estimate", lambda a, b: f"{a['mean_issue_cycles_lower']:.2f} / {a['mean_issue_cycles_estimate']:.2f}")
+    row("`roofline.frac` (VALU issue, lower bound) / `frac_estimate`", lambda a, b: f"{b['roofline']['frac']:.2f} / {b['roofline']['frac_estimate']:.2f}")
+    row("L1 return path: `TD_TD_BUSY` / of which stalled on L2 (`TD_TC_STALL`) / `TA_TA_BUSY`, share of CU-cycles",
+        lambda a, b: f"{a['td_busy_frac']:.2f} / {a['td_tc_stall_frac']:.2f} / {a['ta_busy_frac']:.2f}")
+    row("L1 hit rate / L2 hit rate", lambda a, b: f"{a['l1_hit_rate']:.3f} / {a['l2_hit_rate']:.3f}")
+    row("HBM-side traffic (FETCH_SIZE x2 + WRITE_SIZE), GB per launch / share of the HBM peak",
+        lambda a, b: f"{a['hbm_bytes_per_launch'] / 1e9:.2f} / {b['roofline']['traffic_frac_of_hbm_peak']:.3f}")
+    row("wave-cycles issue-stalled", lambda a, b: f"{a['wave_cycles_issue_stalled_frac']:.2f}")
+    return "\n".join(rows)
+
+
+def k2_counters():
+    m, c3, c4 = _model(), _bench(f"{ROUND}_final_bench.json"), _bench(f"{ROUND}_final_c4_bench.json")
+    s3, s4 = _stats(f"{ROUND}_final_kernel_stats.csv"), _stats(f"{ROUND}_final_c4_kernel_stats.csv")
+    rows = ["| `k_atrous_tile`, per iteration | c3 | c4 |", "|---|---|---|"]
+
+    def row(label, f):
+        rows.append(f"| {label} | {f(m['c3'], c3, s3)} | {f(m['c4'], c4, s4)} |")
+    row("average launch, µs", lambda a, b, s: _us(s, "k_atrous_tile<false>"))
+    row("VALU wave-instructions, M", lambda a, b, s: f"{a['k2_valu_insts_per_iteration'] / 1e6:.1f}")
+    row("`roofline_k2.frac_valu` (lower bound) / `frac_valu_estimate`", lambda a, b, s: f"{b['roofline_k2']['frac_valu']:.2f} / {b['roofline_k2']['frac_valu_estimate']:.2f}")
+    row("HBM-side traffic (FETCH_SIZE + WRITE_SIZE), MB / bytes per pixel / ÷ the algorithmic 14 B/px",
+        lambda a, b, s: f"{a['k2_hbm_bytes_per_iteration'] / 1e6:.1f} / {a['k2_hbm_bytes_per_iteration'] / a['k2_pixels']:.1f} / {a['k2_hbm_bytes_per_iteration'] / a['k2_pixels'] / 14.0:.2f}")
+    row("`roofline_k2.frac` (14 B/px/iteration against the HBM peak)", lambda a, b, s: f"{b['roofline_k2']['frac']:.3f}")
+    return "\n".join(rows)
+
+
+def cpu_baseline():
+    c3 = _bench(f"{ROUND}_final_bench.json")
+    cb = c3["cpu_baseline"]
+    st, c0 = cb["single_thread"], cb["c0_full_frame"]
+    return "\n".join([
+        "| `cpu_baseline` (oracle, `kind: port`, host cores of the GPU box) | Mrays/s | ms per c3 frame (extrapolated by rows) |", "|---|---|---|",
+        f"| {cb['cores']} threads | {cb['value']:.2f} | {cb['frame_ms_extrapolated_by_rows']:.0f} |",
+        f"| 1 thread | {st['value']:.3f} | {st['frame_ms_extrapolated_by_rows']:.0f} |",
+        "",
+        f"c0 (640x360, 4 rays, 2 iterations) as a whole frame on the CPU: {c0['all_cores']['ms_per_frame']:.0f} ms on {c0['all_cores']['cores']} threads, "
+        f"{c0['one_core']['ms_per_frame']:.0f} ms on one."])
+
+
+BLOCKS = {"headline": headline, "kernel_times": kernel_times, "k1_counters": k1_counters, "k2_counters": k2_counters, "cpu_baseline": cpu_baseline}
+_RX = re.compile(r"(<!-- gen:([a-z0-9_]+) -->\n)(.*?)(<!-- /gen:\2 -->)", re.S)
+
+
+def blocks_in(text):
+    """[(name, body)] of the generated blocks of a document."""
+    return [(m.group(2), m.group(3).rstrip("\n")) for m in _RX.finditer(text)]
+
+
+def rewrite(text):
+    return _RX.sub(lambda m: m.group(1) + BLOCKS[m.group(2)]() + "\n" + m.group(4), text)
+
+
+_NUM = re.compile(r"(?<![A-Za-z_0-9])-?\d+(?:\.\d+)?")
+
+
+def compare(doc_body, gen_body, tol=0.10):
+    """None when the block agrees with the generator, else a message: same text around the numbers, numbers within tol."""
+    if _NUM.sub("#", doc_body) != _NUM.sub("#", gen_body):
+        return "text differs from the generator's (run tools/docs_tables.py --write)"
+    for a, b in zip(_NUM.findall(doc_body), _NUM.findall(gen_body)):
+        x, y = float(a), float(b)
+        if abs(x - y) > tol * max(abs(y), 1e-12):
+            return f"documented {a}, evidence {b}"
+    return None
+
+
+def main():
+    write = "--write" in sys.argv
+    bad = 0
+    for name in DOCS:
+        path = os.path.join(ROOT, name)
+        text = open(path).read()
+        if write:
+            new = rewrite(text)
+            if new != text:
+                open(path, "w").write(new)
+                print(f"{name}: rewritten")
+            continue
+        for block, body in blocks_in(text):
+            msg = compare(body, BLOCKS[block]())
+            if msg:
+                bad += 1
+                print(f"{name} [{block}]: {msg}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

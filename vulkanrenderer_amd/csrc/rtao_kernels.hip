@@ -664,11 +664,15 @@ VKR_DI float group8_max(float v)
 constexpr int PIX_ROWS = K1_CUT ? 8 : 4;       // rows of a k_pix_setup / k_pix_resolve block
 
 __global__ __launch_bounds__(64 * PIX_ROWS) void k_pix_setup(FrameParams fp, const uint16_t* depthP, uint16_t* histCurr, uint32_t* hitMask,
-                                                   int y0, int y1, int rows, float4* pixctx, float4* tile_bounds, uint32_t tiles_x)
+                                                   int y0, int y1, int rows, float4* pixctx, float4* tile_bounds, uint32_t tiles_x,
+                                                   uint32_t* item_counters, uint32_t n_counters)
 {
 #if K1_CUT
     __shared__ float s_b[8][8][6];            // [tile of the block][row][lo xyz, hi xyz]
 #endif
+    // k_trace_q's work counters start every launch at zero: cleared here (the kernel before it in the stream) instead of by a
+    // fill kernel of their own
+    if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x < n_counters) item_counters[threadIdx.x] = 0u;
     const int px = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63u);
     const int j = (int)blockIdx.y * PIX_ROWS + (int)(threadIdx.x >> 6);
     const int py = y0 + (j >> 3) * 8 * fp.stripeMul + (j & 7);
@@ -1584,7 +1588,10 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     }
     constexpr uint32_t n_ctr = 16u * (K1_SLABS > 8 ? K1_SLABS : 8);                                              // counters 64 B apart
     if (c->d_tile_counter.n < n_ctr && (e = c->d_tile_counter.alloc(n_ctr)) != hipSuccess) return e;
+    static_assert(n_ctr <= 64u * PIX_ROWS, "k_pix_setup's first block clears the counters");
+#if !K1_SPLIT
     if ((e = hipMemsetAsync(c->d_tile_counter.p, 0, n_ctr * 4u, st)) != hipSuccess) return e;
+#endif
 #if K1_SPLIT
     const size_t npx = (size_t)fp.W * fp.H;
     if (c->d_pixctx.n < 3u * npx || c->d_vis.n < npx) {
@@ -1602,7 +1609,7 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
     }
 #endif
     k_pix_setup<<<dim3(pgrid.x, ((uint32_t)rows + PIX_ROWS - 1u) / PIX_ROWS), 64 * PIX_ROWS, 0, st>>>(
-        fp, depth, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p, c->d_tile_bounds.p, tiles_x);
+        fp, depth, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p, c->d_tile_bounds.p, tiles_x, c->d_tile_counter.p, n_ctr);
 #if K1_CUT
     {
         // third level of the wide tree (levels are contiguous index ranges, recorded by the collapse): k_tile_cut's first round
