@@ -410,8 +410,19 @@ def main():
             ctx.attachCommCustom(gloo_allgather, rank, n)
         else:
             dist.barrier()                                                       # the communicator exists after the first collective
-            backend = dist.distributed_c10d._get_default_group()._get_backend(dev)
-            ctx.attachComm(int(backend._comm_ptr()), rank, n)
+            attached = 1
+            try:
+                backend = dist.distributed_c10d._get_default_group()._get_backend(dev)
+                ctx.attachComm(int(backend._comm_ptr()), rank, n)
+            except Exception as e:                                               # no raw communicator in this torch build, or RCCL refused it
+                attached = 0
+                print(f"[bench rank {rank}] vkr_comm_attach unavailable ({e!r})", file=sys.stderr, flush=True)
+            flag = torch.tensor([attached], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)                          # every rank takes the same path
+            if int(flag.item()) == 0:
+                if attached:
+                    ctx.attachComm(0, 0, 0)                                      # detach
+                capi_comm = False                                                # the torch.distributed gathers, like VKR_BENCH_TORCH_COMM=1
 
     pending = []   # the [rtao_full | sun] gather of the previous frame, still in flight on the communicator's stream
 

@@ -305,6 +305,45 @@ def test_sun_and_point_shadows_match_oracle(torch_mod, oracle_mod):
     ctx.close()
 
 
+@pytest.mark.parametrize("W,H", [(67, 45), (8, 8), (130, 7), (9, 70)])
+def test_shadow_chunks_as_tiles_ragged_sizes_and_the_linear_fallback(torch_mod, oracle_mod, W, H):
+    """The shadow kernels cut arrays that are rows of the context's image into 8x8 tiles (widths and heights that are no multiple
+    of 8, a band that starts between tile rows), and anything else -- here: the frame without its last 5 pixels -- into runs of
+    pixels; VKR_SUN_TILES=0 is the all-runs form.  Every pixel against the oracle, sun (packets) and point lights."""
+    import ctypes as C
+    from vulkanrenderer_amd import FrameState, make_street_scene, camera_path
+    from vulkanrenderer_amd.renderer import ShadowRays
+    from vulkanrenderer_amd.scenes import UBO_DIR_LIGHT_PARAMS
+    O = oracle_mod
+    scene = make_street_scene(13, 0.02, "shadow")
+    ctx, rt, gb = _ctx(scene, W, H)
+    osc = O.OracleScene(scene)
+    sh = ShadowRays(ctx, gb)
+    fs = FrameState(W, H, sun_radius=0.02, sun_samples=16, point_lights=1)
+    ubo = fs.update(*camera_path(scene, 1)[0])
+    depth, normal, wp, ng, valid = osc.gbuffer(ubo, W, H)
+    gb.upload(depth, normal, wp, ng, valid)
+    ref = osc.shadow_sun(wp, ng, valid, FrameState.sun_dir_to_light(ubo), 0.02, 16).view(np.uint32)
+    assert np.array_equal(sh.sun(ubo).cpu().numpy().view(np.uint32), ref)
+    refp = osc.shadow_point(wp, ng, valid, ubo[60:63]).view(np.uint32)
+    assert np.array_equal(sh.point(ubo, 0).cpu().numpy().view(np.uint32), refp)
+    if H > 12:
+        sh.sun_vis.zero_()
+        part = sh.sun(ubo, rows=(3, H - 4)).cpu().numpy().view(np.uint32)      # a band that starts and ends between tile rows
+        assert np.array_equal(part[3:H - 4], ref[3:H - 4]) and not part[:3].any() and not part[H - 4:].any()
+    if W * H > 5:
+        # count is no multiple of the width: runs of pixels
+        sh.sun_vis.fill_(7.0)
+        L = (C.c_float * 3)(*[float(x) for x in FrameState.sun_dir_to_light(ubo)])
+        rc = ctx.lib.vkr_shadow_sun(ctx.handle, gb.world_pos.data_ptr(), gb.geom_normal.data_ptr(), gb.valid.data_ptr(), W * H - 5, L,
+                                    float(ubo[UBO_DIR_LIGHT_PARAMS]), float(ubo[UBO_DIR_LIGHT_PARAMS + 1]), sh.sun_vis.data_ptr(), ctx.stream())
+        assert rc == 0
+        ctx.sync()
+        got = sh.sun_vis.cpu().numpy().reshape(-1)
+        assert np.array_equal(got[:-5].view(np.uint32), ref.reshape(-1)[:-5]) and np.all(got[-5:] == 7.0)
+    ctx.close()
+
+
 def _band_vs_full(scene, W, H, rays, iters, n, frames, step=0.05):
     """N contexts on one GPU, each executing its band (+halo) and exchanging [history | rtao_full] exactly as
     bench.py does over RCCL (pack / gather / unpack), against one context running the full frame."""

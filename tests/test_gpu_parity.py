@@ -88,6 +88,14 @@ def test_ragged_sizes_ray_counts_and_iterations(torch_mod, oracle_mod, W, H, ray
     _run_chain(make_test_scene(), W, H, rays, iters, 2, torch_mod, f"{W}x{H} r{rays} i{iters}")
 
 
+def test_reference_default_five_iterations_at_an_odd_hd_size(torch_mod, oracle_mod):
+    """The reference ships 5 A-Trous iterations (steps 1..16, AppConfig.h:88-96).  At 1283x725 the step-16 iteration has 256
+    comb sub-images of 81x46 texels, ragged in both directions, and the work items of k_atrous_tile do not divide by the 8 XCD
+    runs they are dealt out in: every pixel of rtao_full and of the history against the oracle."""
+    from vulkanrenderer_amd import make_sponza_class
+    _run_chain(make_sponza_class(), 1283, 725, 2, 5, 1, torch_mod, "1283x725 r2 i5")
+
+
 def test_ray_count_is_clamped_like_the_shader(torch_mod, oracle_mod):
     # rtao_trace_half.comp:252 clamps rayCount to [1, 16]; 40 and 0 must behave as 16 and 1 on both sides
     from vulkanrenderer_amd import make_test_scene

@@ -132,7 +132,19 @@ def cpu_baseline():
         f"{c0['one_core']['ms_per_frame']:.0f} ms on one."])
 
 
-BLOCKS = {"headline": headline, "kernel_times": kernel_times, "k1_counters": k1_counters, "k2_counters": k2_counters, "cpu_baseline": cpu_baseline}
+def targets():
+    c3 = _bench(f"{ROUND}_final_bench.json")
+    s3 = _stats(f"{ROUND}_final_kernel_stats.csv")
+    k = c3["kernels"]
+    around = (s3["k_pix_setup"][1] + s3["k_tile_cut"][1] + s3["k_pix_resolve"][1]) / 1e3
+    return (f"**Targets.** >= 1 Grays/s: met ({c3['value'] / 1e3:.1f} Grays/s). `< 2 ms trace + temporal + 4 x A-Trous` at C3: **not met**, "
+            f"{c3['ms_per_step']:.2f} ms (3.44 in round 1, 2.59 in round 2). VERDICT r2 asked for `k_trace_q` <= 1.95 ms and a step <= 2.2 ms: the kernel is at "
+            f"{s3['k_trace_q<false, 7>'][1] / 1e3:.2f} ms (rocprofv3 average), the step is not there: {k['trace_ms']:.2f} ms of K1 ({around:.2f} ms of it the three "
+            f"streaming kernels around `k_trace_q`) + {k['atrous_total_ms']:.2f} ms of A-Trous at >= {c3['roofline_k2']['frac_valu']:.2f} of its VALU bound. "
+            f"What is left is in section 9.")
+
+
+BLOCKS = {"targets": targets, "headline": headline, "kernel_times": kernel_times, "k1_counters": k1_counters, "k2_counters": k2_counters, "cpu_baseline": cpu_baseline}
 _RX = re.compile(r"(<!-- gen:([a-z0-9_]+) -->\n)(.*?)(<!-- /gen:\2 -->)", re.S)
 
 

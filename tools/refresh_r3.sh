@@ -31,6 +31,7 @@ cd $R
 python3 tools/make_valu_model.py r3_final:c3 r3_final_c4:c4 > /dev/null
 tools/grun.sh 600 'timeout -k 10 400 python3 bench.py > gpurun_out/r3_final_bench.json 2> gpurun_out/r3_final_bench.err; echo done' | tail -1
 cp gpurun_out/r3_final_bench.json profiles/r3_final_bench.json
+python3 tools/docs_tables.py --write          # the result tables of DESIGN.md / BASELINE.md / README.md follow the new evidence
 python3 - <<'PY'
 import json,csv
 d=json.loads(open('/root/repo/profiles/r3_final_bench.json').read().strip().splitlines()[-1]); r=d['roofline']

@@ -176,6 +176,8 @@ struct vkr_ctx {
     uint32_t cut_l2_begin = 0, cut_l2_count = 0;   // third level of the wide tree, when k_tile_cut may start there (vkr_bvh_build)
     uint32_t cut_max = 16;                   // entries per cut at most (VKR_CUT_MAX, <= K1_CUT_MAX)
     float cut_small = 1.0f;                  // a node joins the cut once its half area is <= this x the half area of the tile's ray bound (VKR_CUT_SMALL)
+    bool cut_fused = true;                   // the cuts are made by k_pix_setup's own waves (VKR_CUT_FUSED=0: by a k_tile_cut launch after it)
+    bool sun_tiles = true;                   // sun packets: chunks are 8x8 tiles when the arrays are rows of the image (VKR_SUN_TILES=0: runs along a row)
     vkr::DevBuf<float4> d_nz;                // decoded normal.xyz + clamped depth: operand plane of the gather form of A-Trous (VKR_ATROUS=gather) only
     const uint16_t* at_depth = nullptr;      // the frame's A-Trous operands as the caller handed them over (rtao_prep_launch) ...
     const uint16_t* at_normal = nullptr;

@@ -653,107 +653,6 @@ __host__ __device__ inline int q_item_pixels(int rb, int rayCount)
 // K1_CUT: the block is 64 pixels x the 8 rows of one stripe = eight 8x8 tiles, and it also leaves the bound of every tile's ray
 // segments for k_tile_cut (2 float4 per tile: minimum corner | valid flag, maximum corner): per pixel the half ball of radius
 // `radius + largest origin offset` around the offset origin (:375,418-430), reduced over the tile.
-VKR_DI float group8_min(float v)
-{
-    v = gmin(v, __shfl_xor(v, 1, 64)); v = gmin(v, __shfl_xor(v, 2, 64)); return gmin(v, __shfl_xor(v, 4, 64));
-}
-VKR_DI float group8_max(float v)
-{
-    v = gmax(v, __shfl_xor(v, 1, 64)); v = gmax(v, __shfl_xor(v, 2, 64)); return gmax(v, __shfl_xor(v, 4, 64));
-}
-constexpr int PIX_ROWS = K1_CUT ? 8 : 4;       // rows of a k_pix_setup / k_pix_resolve block
-
-__global__ __launch_bounds__(64 * PIX_ROWS) void k_pix_setup(FrameParams fp, const uint16_t* depthP, uint16_t* histCurr, uint32_t* hitMask,
-                                                   int y0, int y1, int rows, float4* pixctx, float4* tile_bounds, uint32_t tiles_x,
-                                                   uint32_t* item_counters, uint32_t n_counters)
-{
-#if K1_CUT
-    __shared__ float s_b[8][8][6];            // [tile of the block][row][lo xyz, hi xyz]
-#endif
-    // k_trace_q's work counters start every launch at zero: cleared here (the kernel before it in the stream) instead of by a
-    // fill kernel of their own
-    if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x < n_counters) item_counters[threadIdx.x] = 0u;
-    const int px = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63u);
-    const int j = (int)blockIdx.y * PIX_ROWS + (int)(threadIdx.x >> 6);
-    const int py = y0 + (j >> 3) * 8 * fp.stripeMul + (j & 7);
-    const bool inside = !(px >= fp.W || j >= rows || py >= y1);
-    PixelCtx pc;
-    pc.valid = false;
-    if (inside) {
-        const Img16 depth{depthP, fp.W, fp.H};
-        setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);
-        float4* o = pixctx + 3u * ((size_t)py * fp.W + px);
-        o[0] = make_float4(pc.worldPos.x, pc.worldPos.y, pc.worldPos.z, pc.valid ? pc.viewZ : 0.0f);
-        if (pc.valid) {
-            o[1] = make_float4(pc.geomNormal.x, pc.geomNormal.y, pc.geomNormal.z, pc.radius);
-            o[2] = make_float4(pc.bias, pc.footprint, pc.cs, pc.sn);
-        }
-    }
-#if K1_CUT
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    if (pc.valid) {
-        // a ray runs from o + d * dirOffset to o + d * (dirOffset + radius) with dirOffset <= slope * 1.65 (:421-423,430) and
-        // dot(n, d) >= 0 (:408-412; -0.01 allowed for rounding): inside the half ball of radius R around the offset origin o
-        const float slope = gmax(pc.bias * 0.5f, pc.footprint * 0.02f);
-        const float R = (pc.radius + slope * 1.65f) * 1.0001f + 1.0e-5f;
-        const float oc[3] = {pc.origin.x, pc.origin.y, pc.origin.z}, nc[3] = {pc.geomNormal.x, pc.geomNormal.y, pc.geomNormal.z};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float side = gmin(1.0f, sqrt_(gmax(1.0f - nc[a] * nc[a], 0.0f)) + 0.02f);   // extent against the normal
-            const float pad = 1.0e-4f + __builtin_fabsf(oc[a]) * 1.0e-6f;
-            lo[a] = oc[a] - R * (nc[a] > 0.0f ? side : 1.0f) - pad;
-            hi[a] = oc[a] + R * (nc[a] < 0.0f ? side : 1.0f) + pad;
-        }
-    }
-    const int t8 = (int)(threadIdx.x & 63u) >> 3, r8 = (int)(threadIdx.x >> 6);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float l = group8_min(lo[a]), h = group8_max(hi[a]);
-        if ((threadIdx.x & 7u) == 0u) { s_b[t8][r8][a] = l; s_b[t8][r8][3 + a] = h; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 48u) {
-        const int t = (int)threadIdx.x / 6, a = (int)threadIdx.x % 6;
-        float v = s_b[t][0][a];
-#pragma unroll
-        for (int r = 1; r < 8; ++r) v = (a < 3) ? gmin(v, s_b[t][r][a]) : gmax(v, s_b[t][r][a]);
-        const uint32_t tile_x = blockIdx.x * 8u + (uint32_t)t;
-        if (tile_x < tiles_x) ((float*)(tile_bounds + 2u * ((size_t)blockIdx.y * tiles_x + tile_x)))[a < 3 ? a : a + 1] = v;
-    }
-#endif
-}
-
-__global__ __launch_bounds__(256) void k_pix_resolve(FrameParams fp, const uint16_t* depthP, const uint16_t* histPrevP, uint16_t* histCurr,
-                                                     uint32_t* hitMask, int y0, int y1, int rows, const float4* pixctx, const float2* vis)
-{
-    const int px = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63u);
-    const int j = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
-    const int py = y0 + (j >> 3) * 8 * fp.stripeMul + (j & 7);
-    if (px >= fp.W || j >= rows || py >= y1) return;
-    const size_t o = (size_t)py * fp.W + px;
-    const float4 c0 = pixctx[3u * o];
-    if (!(c0.w > 0.0f)) return;                                 // early-out pixels stored their value in k_pix_setup
-    const Img16 depth{depthP, fp.W, fp.H}, histPrev{histPrevP, fp.W, fp.H};
-    const float2 v = vis[o];
-    PixelCtx pc;
-    pc.viewZ = c0.w; pc.worldPos = V3{c0.x, c0.y, c0.z};
-    resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc, v.x, f2u(v.y));
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1_CUT: the entry cut of an 8x8 tile.  AO rays are short (tMax = radius <= 1.92 m, :371-372,430) and the pixels of a tile
-// are centimetres apart, so all rays of a tile live in one small box -- and every one of them would walk the same upper
-// levels of the tree to get there (about a third of its node visits).  k_tile_cut walks them ONCE per tile: one wave per
-// tile bounds the tile's ray segments (per pixel: the hemisphere of radius `radius + largest origin offset` around the
-// offset origin, :375,418-430), then descends from the root through every child whose box overlaps that bound, level by
-// level (up to 16 open nodes x 4 children on the 64 lanes), until the nodes are no larger than the bound (`small_factor`),
-// are leaves, or the cut would exceed `cut_max` entries (then the nodes still open join the cut as they are).  A cut entry is
-// 16 bytes: the child's box clipped to the bound, as six fp16 offsets from the bound's minimum corner (widened outward by
-// more than the fp16 rounding), and the child reference.  k_trace_q tests every ray of an item against the tile's entries
-// (uniform LDS reads, two rays per lane) and queues it at the entries it overlaps, instead of queueing it at the root.
-// Box tests are conservative, so the closest committed hit of every ray -- and with it every output bit -- is unchanged.
-// Record per tile: [0] bound minimum xyz | number of entries, [1 ..] entries.
-// ---------------------------------------------------------------------------------------------
 VKR_DI uint32_t pack_h2(float a, float b)
 {
     return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
@@ -761,16 +660,12 @@ VKR_DI uint32_t pack_h2(float a, float b)
 VKR_DI float h_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
 VKR_DI float h_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
 
-__global__ __launch_bounds__(64) void k_tile_cut(SceneDev sc, uint32_t n_tiles, const float4* tile_bounds, uint4* cuts, uint32_t cut_max,
-                                                 float small_factor, uint32_t l2_begin, uint32_t l2_count)
+// One wave: the entry cut of the tile whose ray segments lie in [amin, amax] (amin.x > amax.x: the tile casts no rays).  `s_open` is 16
+// uint4 of LDS owned by this wave.
+VKR_DI void tile_cut_wave(const SceneDev& sc, uint32_t tile, const float* amin, const float* amax, uint4* cuts, uint32_t cut_max, float small_factor,
+                          uint32_t l2_begin, uint32_t l2_count, uint4* s_open, int lane)
 {
-    __shared__ uint4 s_open[16];
-    const int lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
     uint4* out = cuts + (size_t)tile * (K1_CUT_MAX + 1);
-    const float4 b0 = tile_bounds[2u * (size_t)tile], b1 = tile_bounds[2u * (size_t)tile + 1u];   // k_pix_setup: bound of the tile's ray segments
-    const float amin[3] = {b0.x, b0.y, b0.z}, amax[3] = {b1.x, b1.y, b1.z};
     uint32_t ncut = 0;
     if (amin[0] <= amax[0] && sc.tri_count != 0u) {
         const float ex = amax[0] - amin[0], ey = amax[1] - amin[1], ez = amax[2] - amin[2];
@@ -827,6 +722,134 @@ __global__ __launch_bounds__(64) void k_tile_cut(SceneDev sc, uint32_t n_tiles, 
     if (lane == 0) out[0] = make_uint4(f2u(amin[0]), f2u(amin[1]), f2u(amin[2]), ncut);
 }
 
+__global__ __launch_bounds__(64) void k_tile_cut(SceneDev sc, uint32_t n_tiles, const float4* tile_bounds, uint4* cuts, uint32_t cut_max,
+                                                 float small_factor, uint32_t l2_begin, uint32_t l2_count)
+{
+    __shared__ uint4 s_open[16];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const float4 b0 = tile_bounds[2u * (size_t)tile], b1 = tile_bounds[2u * (size_t)tile + 1u];   // k_pix_setup: bound of the tile's ray segments
+    const float amin[3] = {b0.x, b0.y, b0.z}, amax[3] = {b1.x, b1.y, b1.z};
+    tile_cut_wave(sc, tile, amin, amax, cuts, cut_max, small_factor, l2_begin, l2_count, s_open, (int)threadIdx.x);
+}
+
+VKR_DI float group8_min(float v)
+{
+    v = gmin(v, __shfl_xor(v, 1, 64)); v = gmin(v, __shfl_xor(v, 2, 64)); return gmin(v, __shfl_xor(v, 4, 64));
+}
+VKR_DI float group8_max(float v)
+{
+    v = gmax(v, __shfl_xor(v, 1, 64)); v = gmax(v, __shfl_xor(v, 2, 64)); return gmax(v, __shfl_xor(v, 4, 64));
+}
+constexpr int PIX_ROWS = K1_CUT ? 8 : 4;       // rows of a k_pix_setup / k_pix_resolve block
+
+__global__ __launch_bounds__(64 * PIX_ROWS) void k_pix_setup(FrameParams fp, const uint16_t* depthP, uint16_t* histCurr, uint32_t* hitMask,
+                                                   int y0, int y1, int rows, float4* pixctx, float4* tile_bounds, uint32_t tiles_x,
+                                                   uint32_t* item_counters, uint32_t n_counters,
+                                                   SceneDev sc, uint4* cuts, uint32_t cut_max, float cut_small, uint32_t l2_begin, uint32_t l2_count)
+{
+#if K1_CUT
+    __shared__ float s_b[8][8][6];            // [tile of the block][row][lo xyz, hi xyz]
+    __shared__ float s_tb[8][8];              // [tile of the block][lo xyz, hi xyz]: the reduced bounds, for the fused cut
+    __shared__ uint4 s_open[8][16];           // tile_cut_wave's open list, one per wave
+#endif
+    // k_trace_q's work counters start every launch at zero: cleared here (the kernel before it in the stream) instead of by a
+    // fill kernel of their own
+    if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x < n_counters) item_counters[threadIdx.x] = 0u;
+    const int px = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63u);
+    const int j = (int)blockIdx.y * PIX_ROWS + (int)(threadIdx.x >> 6);
+    const int py = y0 + (j >> 3) * 8 * fp.stripeMul + (j & 7);
+    const bool inside = !(px >= fp.W || j >= rows || py >= y1);
+    PixelCtx pc;
+    pc.valid = false;
+    if (inside) {
+        const Img16 depth{depthP, fp.W, fp.H};
+        setup_pixel(fp, depth, histCurr, hitMask, px, py, pc);
+        float4* o = pixctx + 3u * ((size_t)py * fp.W + px);
+        o[0] = make_float4(pc.worldPos.x, pc.worldPos.y, pc.worldPos.z, pc.valid ? pc.viewZ : 0.0f);
+        if (pc.valid) {
+            o[1] = make_float4(pc.geomNormal.x, pc.geomNormal.y, pc.geomNormal.z, pc.radius);
+            o[2] = make_float4(pc.bias, pc.footprint, pc.cs, pc.sn);
+        }
+    }
+#if K1_CUT
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (pc.valid) {
+        // a ray runs from o + d * dirOffset to o + d * (dirOffset + radius) with dirOffset <= slope * 1.65 (:421-423,430) and
+        // dot(n, d) >= 0 (:408-412; -0.01 allowed for rounding): inside the half ball of radius R around the offset origin o
+        const float slope = gmax(pc.bias * 0.5f, pc.footprint * 0.02f);
+        const float R = (pc.radius + slope * 1.65f) * 1.0001f + 1.0e-5f;
+        const float oc[3] = {pc.origin.x, pc.origin.y, pc.origin.z}, nc[3] = {pc.geomNormal.x, pc.geomNormal.y, pc.geomNormal.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float side = gmin(1.0f, sqrt_(gmax(1.0f - nc[a] * nc[a], 0.0f)) + 0.02f);   // extent against the normal
+            const float pad = 1.0e-4f + __builtin_fabsf(oc[a]) * 1.0e-6f;
+            lo[a] = oc[a] - R * (nc[a] > 0.0f ? side : 1.0f) - pad;
+            hi[a] = oc[a] + R * (nc[a] < 0.0f ? side : 1.0f) + pad;
+        }
+    }
+    const int t8 = (int)(threadIdx.x & 63u) >> 3, r8 = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = group8_min(lo[a]), h = group8_max(hi[a]);
+        if ((threadIdx.x & 7u) == 0u) { s_b[t8][r8][a] = l; s_b[t8][r8][3 + a] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 48u) {
+        const int t = (int)threadIdx.x / 6, a = (int)threadIdx.x % 6;
+        float v = s_b[t][0][a];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v = (a < 3) ? gmin(v, s_b[t][r][a]) : gmax(v, s_b[t][r][a]);
+        const uint32_t tile_x = blockIdx.x * 8u + (uint32_t)t;
+        if (cuts) s_tb[t][a] = v;
+        else if (tile_x < tiles_x) ((float*)(tile_bounds + 2u * ((size_t)blockIdx.y * tiles_x + tile_x)))[a < 3 ? a : a + 1] = v;
+    }
+    // The entry cuts of the block's eight tiles, one per wave, in the same launch (cuts != nullptr; else k_tile_cut does it from
+    // tile_bounds): the descent is a short chain of dependent loads, which the other blocks' streaming work covers.
+    if (cuts) {
+        __syncthreads();
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const uint32_t tile_x = blockIdx.x * 8u + w;
+        if (tile_x < tiles_x) {
+            const float amin[3] = {s_tb[w][0], s_tb[w][1], s_tb[w][2]}, amax[3] = {s_tb[w][3], s_tb[w][4], s_tb[w][5]};
+            tile_cut_wave(sc, blockIdx.y * tiles_x + tile_x, amin, amax, cuts, cut_max, cut_small, l2_begin, l2_count, s_open[w],
+                          (int)(threadIdx.x & 63u));
+        }
+    }
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_pix_resolve(FrameParams fp, const uint16_t* depthP, const uint16_t* histPrevP, uint16_t* histCurr,
+                                                     uint32_t* hitMask, int y0, int y1, int rows, const float4* pixctx, const float2* vis)
+{
+    const int px = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63u);
+    const int j = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    const int py = y0 + (j >> 3) * 8 * fp.stripeMul + (j & 7);
+    if (px >= fp.W || j >= rows || py >= y1) return;
+    const size_t o = (size_t)py * fp.W + px;
+    const float4 c0 = pixctx[3u * o];
+    if (!(c0.w > 0.0f)) return;                                 // early-out pixels stored their value in k_pix_setup
+    const Img16 depth{depthP, fp.W, fp.H}, histPrev{histPrevP, fp.W, fp.H};
+    const float2 v = vis[o];
+    PixelCtx pc;
+    pc.viewZ = c0.w; pc.worldPos = V3{c0.x, c0.y, c0.z};
+    resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc, v.x, f2u(v.y));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1_CUT: the entry cut of an 8x8 tile.  AO rays are short (tMax = radius <= 1.92 m, :371-372,430) and the pixels of a tile
+// are centimetres apart, so all rays of a tile live in one small box -- and every one of them would walk the same upper
+// levels of the tree to get there (about a third of its node visits).  k_tile_cut walks them ONCE per tile: one wave per
+// tile bounds the tile's ray segments (per pixel: the hemisphere of radius `radius + largest origin offset` around the
+// offset origin, :375,418-430), then descends from the root through every child whose box overlaps that bound, level by
+// level (up to 16 open nodes x 4 children on the 64 lanes), until the nodes are no larger than the bound (`small_factor`),
+// are leaves, or the cut would exceed `cut_max` entries (then the nodes still open join the cut as they are).  A cut entry is
+// 16 bytes: the child's box clipped to the bound, as six fp16 offsets from the bound's minimum corner (widened outward by
+// more than the fp16 rounding), and the child reference.  k_trace_q tests every ray of an item against the tile's entries
+// (uniform LDS reads, two rays per lane) and queues it at the entries it overlaps, instead of queueing it at the root.
+// Box tests are conservative, so the closest committed hit of every ray -- and with it every output bit -- is unchanged.
+// Record per tile: [0] bound minimum xyz | number of entries, [1 ..] entries.
+// ---------------------------------------------------------------------------------------------
 struct NodeIn { float4 a, b, q0, q1, q2, q3; uint32_t rayhi; };   // one popped node item with its operands in flight
 
 template <bool STATS, int RB>
@@ -1608,15 +1631,16 @@ static hipError_t trace_q_launch(vkr_ctx* c, const SceneDev& sc, const FramePara
         if ((e = c->d_cuts.alloc(ncut4)) != hipSuccess || (e = c->d_tile_bounds.alloc(nb4)) != hipSuccess) return e;
     }
 #endif
+    const uint32_t cut_max = c->cut_max < (uint32_t)K1_CUT_MAX ? c->cut_max : (uint32_t)K1_CUT_MAX;
+    const bool fused = K1_CUT && c->cut_fused;
     k_pix_setup<<<dim3(pgrid.x, ((uint32_t)rows + PIX_ROWS - 1u) / PIX_ROWS), 64 * PIX_ROWS, 0, st>>>(
-        fp, depth, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p, c->d_tile_bounds.p, tiles_x, c->d_tile_counter.p, n_ctr);
+        fp, depth, hist_curr, hit_mask, y0, y1, rows, c->d_pixctx.p, c->d_tile_bounds.p, tiles_x, c->d_tile_counter.p, n_ctr,
+        sc, fused ? c->d_cuts.p : nullptr, cut_max, c->cut_small, c->cut_l2_begin, c->cut_l2_count);
 #if K1_CUT
-    {
+    if (!fused) {
         // third level of the wide tree (levels are contiguous index ranges, recorded by the collapse): k_tile_cut's first round
         const uint32_t l2_begin = c->cut_l2_begin, l2_count = c->cut_l2_count;    // 0 nodes: descend from the root
-        k_tile_cut<<<tiles_x * tiles_y, 64, 0, st>>>(sc, tiles_x * tiles_y, c->d_tile_bounds.p, c->d_cuts.p,
-                                                     c->cut_max < (uint32_t)K1_CUT_MAX ? c->cut_max : (uint32_t)K1_CUT_MAX, c->cut_small,
-                                                     l2_begin, l2_count);
+        k_tile_cut<<<tiles_x * tiles_y, 64, 0, st>>>(sc, tiles_x * tiles_y, c->d_tile_bounds.p, c->d_cuts.p, cut_max, c->cut_small, l2_begin, l2_count);
     }
 #endif
 #endif

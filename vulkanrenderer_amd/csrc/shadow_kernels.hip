@@ -306,8 +306,18 @@ struct ShadowArgs {
 
 template <int MODE>
 __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uint32_t n_chunks, float4* rayBuf,
-                                                 uint32_t* chunk_counter)
+                                                 uint32_t* chunk_counter, uint32_t width)
 {
+    // width != 0: the arrays are rows of `width` pixels and a chunk is 1 (sun) or SQ_POINT_PIX / 64 (point) neighbouring 8x8 tiles
+    // instead of a run of pixels along a row (k_shadow_sun_pkt has the same mapping and the reason for it)
+    const uint32_t tiles_x = (width + 7u) >> 3, rows = width ? sa.count / width : 0u;
+    auto pixel_of = [&](uint32_t chunk, uint32_t p) -> uint32_t {           // index into the arrays, or >= sa.count: no such pixel
+        const uint32_t per = MODE == 0 ? 64u : (uint32_t)SQ_POINT_PIX;
+        if (width == 0u) return chunk * per + p;
+        const uint32_t t = chunk * (per >> 6) + (p >> 6);
+        const uint32_t x = (t % tiles_x) * 8u + (p & 7u), y = (t / tiles_x) * 8u + ((p >> 3) & 7u);
+        return (x < width && y < rows) ? y * width + x : 0xffffffffu;
+    };
     __shared__ uint32_t s_nq[KQ_NQ];
     __shared__ uint32_t s_lq[KQ_LQ];
     __shared__ uint16_t s_lqr[KQ_LQ];
@@ -356,10 +366,8 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
         if (lane < 32) s_occ[lane] = 0u;
         uint32_t n_rays = 0;                 // rays of this chunk (wave-uniform)
         bool pvalid = false;                 // sun: this lane's pixel casts rays
-        uint32_t pix0 = 0;
         if (MODE == 0) {
-            pix0 = chunk * 64u;
-            const uint32_t i = pix0 + (uint32_t)lane;
+            const uint32_t i = pixel_of(chunk, (uint32_t)lane);
             if (i < sa.count) {
                 if ((sa.valid && !sa.valid[i]) || no_light) sa.out[i] = 1.0f;
                 else {
@@ -372,10 +380,9 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
             }
             n_rays = 64u * (uint32_t)n_samples;          // ray r = sample * 64 + pixel lane; invalid pixels never inject
         } else {
-            pix0 = chunk * (uint32_t)SQ_POINT_PIX;
             for (int j = 0; j < SQ_POINT_PIX / 64; ++j) {
                 const uint32_t r = (uint32_t)j * 64u + (uint32_t)lane;
-                const uint32_t i = pix0 + r;
+                const uint32_t i = pixel_of(chunk, r);
                 float4 a = make_float4(0, 0, 0, -1.0f);   // tMin < 0 marks "no ray"
                 float4 b = make_float4(0, 0, 1, 0), c = make_float4(0, 0, 0, 0);
                 if (i < sa.count) {
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
         // ------------------------------------------------------------------ phase 3: per pixel
         if (MODE == 0) {
             if (pvalid) {
-                const uint32_t i = pix0 + (uint32_t)lane;
+                const uint32_t i = pixel_of(chunk, (uint32_t)lane);
                 float visSum = 0.0f;
                 for (int k = 0; k < n_samples; ++k) {                                // :252-257
                     const uint32_t r = (uint32_t)k * 64u + (uint32_t)lane;
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(64) void k_shadow_q(SceneDev sc, ShadowArgs sa, uin
         } else {
             for (int j = 0; j < SQ_POINT_PIX / 64; ++j) {
                 const uint32_t r = (uint32_t)j * 64u + (uint32_t)lane;
-                const uint32_t i = pix0 + r;
+                const uint32_t i = pixel_of(chunk, r);
                 if (i < sa.count && slice[(size_t)r * 3u].w >= 0.0f)
                     sa.out[i] = ((s_occ[r >> 5] >> (r & 31u)) & 1u) ? 0.0f : 1.0f;   // :182-195
             }
@@ -639,8 +646,18 @@ __global__ void k_sun_setup(V3 L, float sunRadius, float sampleCountF, SunFrame*
 }
 
 __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs sa, const SunFrame* __restrict__ sf,
-                                                       uint32_t n_chunks, uint32_t pix_per_chunk, uint32_t* chunk_counter)
+                                                       uint32_t n_chunks, uint32_t pix_per_chunk, uint32_t* chunk_counter, uint32_t width)
 {
+    // width != 0: the arrays are rows of `width` pixels (count = rows * width) and a chunk is pix_per_chunk / 64 neighbouring 8x8
+    // tiles instead of a run of pixels along a row -- origins centimetres apart in both directions walk the same nodes and
+    // triangles, which is what the L1 hit rate of the node and triangle loads lives on.  Results per pixel do not depend on it.
+    const uint32_t tiles_x = (width + 7u) >> 3, rows = width ? sa.count / width : 0u;
+    auto pixel_of = [&](uint32_t chunk, uint32_t p) -> uint32_t {           // index into the arrays, or >= sa.count: no such pixel
+        if (width == 0u) return chunk * pix_per_chunk + p;
+        const uint32_t t = chunk * (pix_per_chunk >> 6) + (p >> 6);
+        const uint32_t x = (t % tiles_x) * 8u + (p & 7u), y = (t / tiles_x) * 8u + ((p >> 3) & 7u);
+        return (x < width && y < rows) ? y * width + x : 0xffffffffu;
+    };
     // pix_per_chunk: 64, 128 or 256 (<= SP_PIX).  Small launches (row bands of a sharded frame) use small chunks so that
     // the persistent waves still get several chunks each; per-pixel results do not depend on it.
     __shared__ uint32_t s_nq[SP_NQ];       // node items: pixel << 22 | node
@@ -676,13 +693,12 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
         if (lane == 0) chunk = atomicAdd(chunk_counter, 1u);
         chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
         if (chunk >= n_chunks) break;        // every wave reaches this: the counter only grows
-        const uint32_t pix0 = chunk * pix_per_chunk;
 
         // ------------------------------------------------------------------ phase 1: origins
         uint32_t nq = 0, lq = 0, tq = 0;
         for (int j = 0; j < (int)(pix_per_chunk / 64u); ++j) {
             const uint32_t p = (uint32_t)j * 64u + (uint32_t)lane;
-            const uint32_t i = pix0 + p;
+            const uint32_t i = pixel_of(chunk, p);
             bool live = false;
             if (i < sa.count) {
                 if ((sa.valid && !sa.valid[i]) || no_light) sa.out[i] = 1.0f;
@@ -877,7 +893,7 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
         // ------------------------------------------------------------------ phase 3: per pixel
         for (int j = 0; j < (int)(pix_per_chunk / 64u); ++j) {
             const uint32_t p = (uint32_t)j * 64u + (uint32_t)lane;
-            const uint32_t i = pix0 + p;
+            const uint32_t i = pixel_of(chunk, p);
             const uint32_t m = s_mask[p];
             if (i < sa.count && !(m & 0x80000000u)) {
                 const float visSum = (float)(n_dirs - (uint32_t)__popc(m & full));   // :252-257, a sum of 0/1 terms
@@ -892,11 +908,21 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
 #endif
 }
 
+// The chunks of a shadow launch (sun packets, point-light / sun ray queues): arrays that are rows of the context's image (a whole frame, or a row band of it: count is a
+// multiple of the width) are cut into 8x8 tiles, anything else into runs of `pix` pixels (VKR_SUN_TILES=0: always runs).
+static void sun_chunks(const vkr_ctx* c, uint32_t count, uint32_t pix, uint32_t* width, uint32_t* n_chunks)
+{
+    *width = (c->sun_tiles && c->W >= 8u && count % c->W == 0u) ? c->W : 0u;
+    const uint32_t tiles = *width ? ((*width + 7u) / 8u) * ((count / *width + 7u) / 8u) : 0u, per = pix / 64u;
+    *n_chunks = *width ? (tiles + per - 1u) / per : (count + pix - 1u) / pix;
+}
+
 static hipError_t shadow_q_launch(vkr_ctx* c, int mode, const ShadowArgs& sa, hipStream_t st)
 {
     hipError_t e;
     const uint32_t per = mode == 0 ? 64u : (uint32_t)SQ_POINT_PIX;
-    const uint32_t n_chunks = (sa.count + per - 1u) / per;
+    uint32_t width, n_chunks;
+    sun_chunks(c, sa.count, per, &width, &n_chunks);
     int& per_cu = c->shq_per_cu[mode == 0 ? 0 : 1];      // asked of the runtime once per context, not per call
     if (per_cu == 0) {
         if (mode == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_q<0>, 64, 0);
@@ -915,8 +941,8 @@ static hipError_t shadow_q_launch(vkr_ctx* c, int mode, const ShadowArgs& sa, hi
     }
     if (!c->d_shq_counter.p && (e = c->d_shq_counter.alloc(1)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(c->d_shq_counter.p, 0, 4, st)) != hipSuccess) return e;
-    if (mode == 0) k_shadow_q<0><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_shq_raybuf.p, c->d_shq_counter.p);
-    else k_shadow_q<1><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_shq_raybuf.p, c->d_shq_counter.p);
+    if (mode == 0) k_shadow_q<0><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_shq_raybuf.p, c->d_shq_counter.p, width);
+    else k_shadow_q<1><<<blocks, 64, 0, st>>>(scene_dev(c), sa, n_chunks, c->d_shq_raybuf.p, c->d_shq_counter.p, width);
     return hipGetLastError();
 }
 
@@ -944,12 +970,13 @@ hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const
             uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
             uint32_t pix = (uint32_t)SP_PIX;                      // aim for >= 4 chunks per resident wave
             while (pix > 64u && (count + pix - 1u) / pix < 4u * blocks) pix >>= 1;
-            const uint32_t n_chunks = (count + pix - 1u) / pix;
+            uint32_t width, n_chunks;
+            sun_chunks(c, count, pix, &width, &n_chunks);
             if (blocks > n_chunks) blocks = n_chunks;
             // its own chunk counter (and d_sun_frame): this launch may overlap vkr_rtao_* launches of another stream
             if (!c->d_sun_counter.p && (e = c->d_sun_counter.alloc(8)) != hipSuccess) return e;
             if ((e = hipMemsetAsync(c->d_sun_counter.p, 0, 4, st)) != hipSuccess) return e;
-            k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, c->d_sun_counter.p);
+            k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, c->d_sun_counter.p, width);
             return hipGetLastError();
         }
         return shadow_q_launch(c, 0, sa, st);
@@ -1009,9 +1036,10 @@ hipError_t shadow_sun_noalloc_launch(vkr_ctx* c, const float* wp, const float* n
     uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
     uint32_t pix = (uint32_t)SP_PIX;                      // same chunking as shadow_sun_launch
     while (pix > 64u && (count + pix - 1u) / pix < 4u * blocks) pix >>= 1;
-    const uint32_t n_chunks = (count + pix - 1u) / pix;
+    uint32_t width, n_chunks;
+    sun_chunks(c, count, pix, &width, &n_chunks);
     if (blocks > n_chunks) blocks = n_chunks;
-    k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, counter);
+    k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, counter, width);
     return hipGetLastError();
 }
 

@@ -128,6 +128,8 @@ int vkr_create(const vkr_create_desc* desc, vkr_ctx** out)
     if (const char* e = getenv("VKR_K1_EXTRA_LDS")) { int v = atoi(e); c->k1_extra_lds = v < 0 ? 0 : v; }
     if (const char* e = getenv("VKR_CUT_MAX")) { int v = atoi(e); c->cut_max = v < 1 ? 1u : (uint32_t)v; }   // 1 = every ray enters at the root's children
     if (const char* e = getenv("VKR_CUT_SMALL")) { float v = (float)atof(e); if (v > 0.0f) c->cut_small = v; }
+    if (const char* e = getenv("VKR_CUT_FUSED")) c->cut_fused = atoi(e) != 0;
+    if (const char* e = getenv("VKR_SUN_TILES")) c->sun_tiles = atoi(e) != 0;
     if (const char* e = getenv("VKR_ATROUS")) c->atrous_mode = !strcmp(e, "gather") ? 0 : (!strcmp(e, "tol") ? 2 : 1);
     if (const char* e = getenv("VKR_TRACE_MODE")) c->trace_streaming = (e[0] != 'l');   // "lane" = one ray per lane
     if (const char* e = getenv("VKR_GBUFFER_MODE")) c->gbuffer_packets = (e[0] != 'l');  // "lane" = one walk per lane
