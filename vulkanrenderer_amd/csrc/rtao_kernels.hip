@@ -536,8 +536,8 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 
 
 // ---------------------------------------------------------------------------------------------
-// K1, streaming form (the default).  Persistent single-wave workgroups pull work items -- a block of P pixels with
-// all their rays, at most 2^RB rays -- from a counter; inside an item the rays do not own lanes: work lives in wave-wide
+// K1, streaming form (the default).  The waves of persistent workgroups pull work items -- a block of P pixels with
+// all their rays, at most 2^RB rays -- from counters; inside an item the rays do not own lanes: work lives in wave-wide
 // LIFO queues in LDS,
 //     node items  ray << (32-RB) | wide node          leaf items  ray << (32-RB) | first triangle << 1 | count-1
 // and every step pops items of ONE kind, so node steps and leaf steps both run with (nearly) all lanes busy.  A node
@@ -555,7 +555,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 //   * LDS queues of 288 node + 128 leaf + 128 alpha entries; overflow goes to a small global stack per wave, and the step
 //     width is throttled only when LDS + global capacity could run out (strict depth-first bound);
 //   * the per-pixel head and tail of main() run as kernels of their own (K1_SPLIT: k_pix_setup, k_pix_resolve);
-//   * rays enter the tree at the cut of their 8x8 tile (K1_CUT: k_tile_cut), not at the root.
+//   * rays enter the tree at the cut of their 8x8 tile (K1_CUT: tile_cut_wave, run by k_pix_setup's waves), not at the root;
+//   * workgroups of four waves (K1_WG), six per CU: the four waves take the four items of one tile at the same time and share
+//     the CU's L1; the items are numbered tile by tile, eight counters hand them out (one per vertical slab = XCD).
 // ---------------------------------------------------------------------------------------------
 #ifndef K1_WAVES
 #define K1_WAVES 6         // resident waves per SIMD the kernel is compiled for (VGPR budget 512 / K1_WAVES: 80)
@@ -597,12 +599,12 @@ __global__ __launch_bounds__(K1_BLOCK) void k_trace(SceneDev sc, FrameParams fp,
 #define K1_SLOT0_FIRST 1  // node-step appends in reverse slot order, see the fast path of the node step
 #endif
 #ifndef K1_CUT
-#define K1_CUT 1           // 1: rays enter the tree at a per-tile cut (k_tile_cut) instead of at the root, see below
+#define K1_CUT 1           // 1: rays enter the tree at a per-tile cut (tile_cut_wave) instead of at the root, see below
 #endif
 #ifndef K1_CUT_MAX
 #define K1_CUT_MAX 16      // entries of a tile's cut at most (16 B each in LDS, after a 16-byte header)
 #endif
-static_assert(K1_CUT_MAX >= 1 && K1_CUT_MAX <= 16, "k_tile_cut expands every open node of a round on 4 lanes each");
+static_assert(K1_CUT_MAX >= 1 && K1_CUT_MAX <= 16, "tile_cut_wave expands every open node of a round on 4 lanes each");
 constexpr uint32_t K1_GNQ = 4096;      // node-item overflow stack per wave (global)
 constexpr uint32_t K1_GLQ = 512;       // leaf-item overflow per wave (global): one node step pushes <= 4 * 128
 constexpr uint32_t K1_AQ = 128;        // alpha-test queue (LDS): drained whenever it holds a full wave of candidates (draining at one
@@ -660,6 +662,20 @@ VKR_DI uint32_t pack_h2(float a, float b)
 VKR_DI float h_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
 VKR_DI float h_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
 
+// ---------------------------------------------------------------------------------------------
+// K1_CUT: the entry cut of an 8x8 tile.  AO rays are short (tMax = radius <= 1.92 m, :371-372,430) and the pixels of a tile
+// are centimetres apart, so all rays of a tile live in one small box -- and every one of them would walk the same upper
+// levels of the tree to get there (about a third of its node visits).  tile_cut_wave walks them ONCE per tile: one wave per
+// tile bounds the tile's ray segments (per pixel: the hemisphere of radius `radius + largest origin offset` around the
+// offset origin, :375,418-430), then descends from the root through every child whose box overlaps that bound, level by
+// level (up to 16 open nodes x 4 children on the 64 lanes), until the nodes are no larger than the bound (`small_factor`),
+// are leaves, or the cut would exceed `cut_max` entries (then the nodes still open join the cut as they are).  A cut entry is
+// 16 bytes: the child's box clipped to the bound, as six fp16 offsets from the bound's minimum corner (widened outward by
+// more than the fp16 rounding), and the child reference.  k_trace_q tests every ray of an item against the tile's entries
+// (uniform LDS reads, two rays per lane) and queues it at the entries it overlaps, instead of queueing it at the root.
+// Box tests are conservative, so the closest committed hit of every ray -- and with it every output bit -- is unchanged.
+// Record per tile: [0] bound minimum xyz | number of entries, [1 ..] entries.
+// ---------------------------------------------------------------------------------------------
 // One wave: the entry cut of the tile whose ray segments lie in [amin, amax] (amin.x > amax.x: the tile casts no rays).  `s_open` is 16
 // uint4 of LDS owned by this wave.
 VKR_DI void tile_cut_wave(const SceneDev& sc, uint32_t tile, const float* amin, const float* amax, uint4* cuts, uint32_t cut_max, float small_factor,
@@ -836,20 +852,6 @@ __global__ __launch_bounds__(256) void k_pix_resolve(FrameParams fp, const uint1
     resolve_pixel(fp, depth, histPrev, histCurr, hitMask, px, py, pc, v.x, f2u(v.y));
 }
 
-// ---------------------------------------------------------------------------------------------
-// K1_CUT: the entry cut of an 8x8 tile.  AO rays are short (tMax = radius <= 1.92 m, :371-372,430) and the pixels of a tile
-// are centimetres apart, so all rays of a tile live in one small box -- and every one of them would walk the same upper
-// levels of the tree to get there (about a third of its node visits).  k_tile_cut walks them ONCE per tile: one wave per
-// tile bounds the tile's ray segments (per pixel: the hemisphere of radius `radius + largest origin offset` around the
-// offset origin, :375,418-430), then descends from the root through every child whose box overlaps that bound, level by
-// level (up to 16 open nodes x 4 children on the 64 lanes), until the nodes are no larger than the bound (`small_factor`),
-// are leaves, or the cut would exceed `cut_max` entries (then the nodes still open join the cut as they are).  A cut entry is
-// 16 bytes: the child's box clipped to the bound, as six fp16 offsets from the bound's minimum corner (widened outward by
-// more than the fp16 rounding), and the child reference.  k_trace_q tests every ray of an item against the tile's entries
-// (uniform LDS reads, two rays per lane) and queues it at the entries it overlaps, instead of queueing it at the root.
-// Box tests are conservative, so the closest committed hit of every ray -- and with it every output bit -- is unchanged.
-// Record per tile: [0] bound minimum xyz | number of entries, [1 ..] entries.
-// ---------------------------------------------------------------------------------------------
 struct NodeIn { float4 a, b, q0, q1, q2, q3; uint32_t rayhi; };   // one popped node item with its operands in flight
 
 template <bool STATS, int RB>

@@ -645,7 +645,43 @@ __global__ void k_sun_setup(V3 L, float sunRadius, float sampleCountF, SunFrame*
     out->axis[3] = tan_max * 1.001f + 1e-6f;
 }
 
-__global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs sa, const SunFrame* __restrict__ sf,
+#ifndef VKR_SUN_WG
+#define VKR_SUN_WG 4       // waves per k_shadow_sun_pkt workgroup: they take neighbouring chunks at the same time and share the CU's L1 (1 = single waves)
+#endif
+constexpr uint32_t SUN_RING = 16;          // VKR_SUN_WG > 1: units a workgroup keeps published at a time
+
+// A workgroup of WG waves takes UNITS of WG consecutive work items from a global counter, without a barrier: a wave takes the next
+// (unit, slot) of its workgroup from an LDS counter; the wave that gets slot 0 fetches the unit from the global counter and
+// publishes it in a ring of LDS entries {tag, unit, readers}, the others wait for that entry (its publisher is resident and
+// running, so the wait is bounded).  An entry is reused RING units later; its publisher first waits until the WG readers of the
+// previous use have counted themselves in.  Returns false once the counter is drained (every later take of the workgroup says so
+// too).  s_take: 4 + 4 * RING words, [0] = 0 and every tag = 0xffffffff before the first call (then __syncthreads).
+template <uint32_t WG, uint32_t RING>
+VKR_DI bool wg_take(uint32_t* s_take, uint32_t* counter, uint32_t n_units, int lane, uint32_t* unit_out, uint32_t* slot_out)
+{
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(&s_take[0], 1u);
+    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    const uint32_t j = k / WG, wslot = k % WG, ring = 4u + 4u * (j % RING);
+    uint32_t unit = 0xfffffffeu;                                // nothing left
+    if (lane == 0) {
+        if (wslot == 0u) {
+            const uint32_t u = atomicAdd(counter, 1u);
+            if (u < n_units) unit = u;
+            while (__hip_atomic_load(&s_take[ring + 2u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (j / RING) * WG) __builtin_amdgcn_s_sleep(1);
+            __hip_atomic_store(&s_take[ring + 1u], unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&s_take[ring], j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        while (__hip_atomic_load(&s_take[ring], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j) __builtin_amdgcn_s_sleep(1);
+        unit = __hip_atomic_load(&s_take[ring + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_take[ring + 2u], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    *unit_out = unit; *slot_out = wslot;
+    return unit != 0xfffffffeu;
+}
+
+__global__ __launch_bounds__(64 * VKR_SUN_WG) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs sa, const SunFrame* __restrict__ sf,
                                                        uint32_t n_chunks, uint32_t pix_per_chunk, uint32_t* chunk_counter, uint32_t width)
 {
     // width != 0: the arrays are rows of `width` pixels (count = rows * width) and a chunk is pix_per_chunk / 64 neighbouring 8x8
@@ -660,17 +696,27 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
     };
     // pix_per_chunk: 64, 128 or 256 (<= SP_PIX).  Small launches (row bands of a sharded frame) use small chunks so that
     // the persistent waves still get several chunks each; per-pixel results do not depend on it.
-    __shared__ uint32_t s_nq[SP_NQ];       // node items: pixel << 22 | node
-    __shared__ uint32_t s_lq[KQ_LQ];       // leaf items: leaf reference ...
-    __shared__ uint8_t s_lqp[KQ_LQ];       // ... and its pixel (index in the chunk: a byte; the LDS footprint decides how
-                                           // many waves a CU holds: 6 656 B = 24 of them, 7 424 B were 22)
+    // per wave (the waves of a workgroup share nothing but the chunk ring):
+    __shared__ uint32_t s_nq_w[VKR_SUN_WG][SP_NQ];       // node items: pixel << 22 | node
+    __shared__ uint32_t s_lq_w[VKR_SUN_WG][KQ_LQ];       // leaf items: leaf reference ...
+    __shared__ uint8_t s_lqp_w[VKR_SUN_WG][KQ_LQ];       // ... and its pixel (index in the chunk: a byte; the LDS footprint decides how
+                                                         // many waves a CU holds: 6 656 B per wave = 24 of them, 7 424 B were 22)
     static_assert(SP_PIX <= 256, "pixel indices are stored in bytes");
-    __shared__ uint32_t s_mask[SP_PIX];    // per pixel: bit k = sample k is occluded
-    __shared__ float s_ox[SP_PIX], s_oy[SP_PIX], s_oz[SP_PIX];   // per pixel: ray origin
-    __shared__ uint32_t s_tq[SP_TQ];       // triangle items (leaf triangles that passed the cone pre-filter): triangle ...
-    __shared__ uint8_t s_tqp[SP_TQ];       // ... and its pixel
+    __shared__ uint32_t s_mask_w[VKR_SUN_WG][SP_PIX];    // per pixel: bit k = sample k is occluded
+    __shared__ float s_ox_w[VKR_SUN_WG][SP_PIX], s_oy_w[VKR_SUN_WG][SP_PIX], s_oz_w[VKR_SUN_WG][SP_PIX];   // per pixel: ray origin
+    __shared__ uint32_t s_tq_w[VKR_SUN_WG][SP_TQ];       // triangle items (leaf triangles that passed the cone pre-filter): triangle ...
+    __shared__ uint8_t s_tqp_w[VKR_SUN_WG][SP_TQ];       // ... and its pixel
+    const uint32_t wv = VKR_SUN_WG > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+    uint32_t* const s_nq = s_nq_w[wv]; uint32_t* const s_lq = s_lq_w[wv]; uint8_t* const s_lqp = s_lqp_w[wv];
+    uint32_t* const s_mask = s_mask_w[wv]; float* const s_ox = s_ox_w[wv]; float* const s_oy = s_oy_w[wv]; float* const s_oz = s_oz_w[wv];
+    uint32_t* const s_tq = s_tq_w[wv]; uint8_t* const s_tqp = s_tqp_w[wv];
+#if VKR_SUN_WG > 1
+    __shared__ uint32_t s_take[4u + 4u * SUN_RING];
+    if (threadIdx.x < 4u + 4u * SUN_RING) s_take[threadIdx.x] = (threadIdx.x >= 4u && (threadIdx.x & 3u) == 0u) ? 0xffffffffu : 0u;
+    __syncthreads();
+#endif
 
-    const int lane = threadIdx.x;
+    const int lane = VKR_SUN_WG > 1 ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : (int)threadIdx.x;
     const char* node_base = (const char*)sc.nodes;
     const char* tri_base = (const char*)sc.tris;
     const uint32_t n_dirs = sf->n;
@@ -690,9 +736,16 @@ __global__ __launch_bounds__(64) void k_shadow_sun_pkt(SceneDev sc, ShadowArgs s
 
     for (;;) {
         uint32_t chunk = 0;
+#if VKR_SUN_WG > 1
+        uint32_t unit, wslot;
+        if (!wg_take<VKR_SUN_WG, SUN_RING>(s_take, chunk_counter, (n_chunks + VKR_SUN_WG - 1u) / VKR_SUN_WG, lane, &unit, &wslot)) break;
+        chunk = unit * VKR_SUN_WG + wslot;
+        if (chunk >= n_chunks) continue;     // the last unit may be short
+#else
         if (lane == 0) chunk = atomicAdd(chunk_counter, 1u);
         chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
         if (chunk >= n_chunks) break;        // every wave reaches this: the counter only grows
+#endif
 
         // ------------------------------------------------------------------ phase 1: origins
         uint32_t nq = 0, lq = 0, tq = 0;
@@ -946,6 +999,24 @@ static hipError_t shadow_q_launch(vkr_ctx* c, int mode, const ShadowArgs& sa, hi
     return hipGetLastError();
 }
 
+// Grid of a sun-packet launch (c->sun_per_cu known): workgroups, pixels per chunk, chunk shape.
+static void sun_grid(const vkr_ctx* c, uint32_t count, uint32_t* blocks, uint32_t* pix, uint32_t* width, uint32_t* n_chunks)
+{
+    // Wave slots per CU this persistent launch leaves free (4; VKR_SUN_RESERVE_WAVES).  A full launch holds 456 of the 512 VGPRs of
+    // every SIMD until its last chunk is done: a kernel issued while it runs -- the A-Trous launches of the same frame on another
+    // stream, a collective's kernel of a multi-GPU host -- would wait for exactly that.  Measured cost of the reserve: none.
+    int waves = c->sun_per_cu * VKR_SUN_WG;
+    if (c->sun_reserve_waves > 0) waves = waves > c->sun_reserve_waves ? waves - c->sun_reserve_waves : 1;
+    const int per_cu = waves / VKR_SUN_WG > 0 ? waves / VKR_SUN_WG : 1;
+    uint32_t b = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
+    uint32_t px = (uint32_t)SP_PIX;                           // aim for >= 4 chunks per resident wave
+    while (px > 64u && (count + px - 1u) / px < 4u * b * VKR_SUN_WG) px >>= 1;
+    sun_chunks(c, count, px, width, n_chunks);
+    const uint32_t units = (*n_chunks + VKR_SUN_WG - 1u) / VKR_SUN_WG;
+    *blocks = b > units ? units : b;
+    *pix = px;
+}
+
 hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const uint8_t* valid, uint32_t count,
                              const float L[3], float radius, float samples, float* out, hipStream_t st)
 {
@@ -958,25 +1029,15 @@ hipError_t shadow_sun_launch(vkr_ctx* c, const float* wp, const float* ng, const
             SunFrame* sf = (SunFrame*)c->d_sun_frame.p;
             k_sun_setup<<<1, 64, 0, st>>>(sa.L, radius, samples, sf);
             if (c->sun_per_cu == 0) {                         // asked of the runtime once per context, not per call
-                if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
+                if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64 * VKR_SUN_WG, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
                 if (c->sun_per_cu < 1) c->sun_per_cu = 1;
             }
-            int per_cu = c->sun_per_cu;
-            // Wave slots per CU this persistent launch leaves free (4; VKR_SUN_RESERVE_WAVES).  A full launch holds 456 of the
-            // 512 VGPRs of every SIMD until its last chunk is done: a kernel issued while it runs -- the A-Trous launches of
-            // the same frame on another stream, a collective's kernel of a multi-GPU host -- would wait for exactly that.
-            // Measured cost of the reserve: none (3.29 vs 3.27 ms at 4K).
-            if (c->sun_reserve_waves > 0) per_cu = per_cu > c->sun_reserve_waves ? per_cu - c->sun_reserve_waves : 1;
-            uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
-            uint32_t pix = (uint32_t)SP_PIX;                      // aim for >= 4 chunks per resident wave
-            while (pix > 64u && (count + pix - 1u) / pix < 4u * blocks) pix >>= 1;
-            uint32_t width, n_chunks;
-            sun_chunks(c, count, pix, &width, &n_chunks);
-            if (blocks > n_chunks) blocks = n_chunks;
+            uint32_t blocks, pix, width, n_chunks;
+            sun_grid(c, count, &blocks, &pix, &width, &n_chunks);
             // its own chunk counter (and d_sun_frame): this launch may overlap vkr_rtao_* launches of another stream
             if (!c->d_sun_counter.p && (e = c->d_sun_counter.alloc(8)) != hipSuccess) return e;
             if ((e = hipMemsetAsync(c->d_sun_counter.p, 0, 4, st)) != hipSuccess) return e;
-            k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, c->d_sun_counter.p, width);
+            k_shadow_sun_pkt<<<blocks, 64 * VKR_SUN_WG, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, c->d_sun_counter.p, width);
             return hipGetLastError();
         }
         return shadow_q_launch(c, 0, sa, st);
@@ -1028,18 +1089,12 @@ hipError_t shadow_sun_noalloc_launch(vkr_ctx* c, const float* wp, const float* n
     if ((e = hipMemsetAsync(counter, 0, 256, st)) != hipSuccess) return e;      // the last call left its chunk count here
     k_sun_setup<<<1, 64, 0, st>>>(sa.L, radius, samples, sf);
     if (c->sun_per_cu == 0) {                                 // normally known since vkr_bvh_build (shadow_prepare)
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64 * VKR_SUN_WG, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
         if (c->sun_per_cu < 1) c->sun_per_cu = 1;
     }
-    int per_cu = c->sun_per_cu;
-    if (c->sun_reserve_waves > 0) per_cu = per_cu > c->sun_reserve_waves ? per_cu - c->sun_reserve_waves : 1;
-    uint32_t blocks = (uint32_t)per_cu * (uint32_t)(c->num_cus > 0 ? c->num_cus : 256);
-    uint32_t pix = (uint32_t)SP_PIX;                      // same chunking as shadow_sun_launch
-    while (pix > 64u && (count + pix - 1u) / pix < 4u * blocks) pix >>= 1;
-    uint32_t width, n_chunks;
-    sun_chunks(c, count, pix, &width, &n_chunks);
-    if (blocks > n_chunks) blocks = n_chunks;
-    k_shadow_sun_pkt<<<blocks, 64, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, counter, width);
+    uint32_t blocks, pix, width, n_chunks;                   // same grid and chunking as shadow_sun_launch
+    sun_grid(c, count, &blocks, &pix, &width, &n_chunks);
+    k_shadow_sun_pkt<<<blocks, 64 * VKR_SUN_WG, 0, st>>>(scene_dev(c), sa, sf, n_chunks, pix, counter, width);
     return hipGetLastError();
 }
 
@@ -1049,7 +1104,7 @@ hipError_t shadow_prepare(vkr_ctx* c)
 {
     hipError_t e;
     if (c->sun_per_cu == 0) {
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->sun_per_cu, k_shadow_sun_pkt, 64 * VKR_SUN_WG, 0)) != hipSuccess) { c->sun_per_cu = 0; return e; }
         if (c->sun_per_cu < 1) c->sun_per_cu = 1;
     }
     if (!c->d_sun_frame.p && (e = c->d_sun_frame.alloc(sizeof(SunFrame))) != hipSuccess) return e;
