@@ -110,6 +110,11 @@ constexpr int K1Q_BLOCK = 64 * K1_WG;        // k_trace_q
 #ifndef K1_UNIT_TILES
 #define K1_UNIT_TILES 1    // K1_WG > 1: 8x8 tiles a workgroup fetches from the counters at a time
 #endif
+#ifdef VKR_EXP_RUNS
+#define K1_EXP_RUNS_ON 1
+#else
+#define K1_EXP_RUNS_ON 0
+#endif
 constexpr uint32_t K1_RING = 16;             // K1_WG > 1: units a workgroup keeps published at a time
 
 VKR_DI uint32_t ray_slice_float4s(int rayCount) { return (uint32_t)rayCount * 64u * 2u + (uint32_t)rayCount * 16u; }
@@ -1218,7 +1223,7 @@ __global__ __launch_bounds__(K1Q_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WA
                             const bool f0 = (int)e0.w < 0, f1 = (int)e1.w < 0, f2 = (int)e2.w < 0, f3 = (int)e3.w < 0;    // wave-uniform: leaf entries
                             const uint32_t totn = (f0 ? 0u : n0) + (f1 ? 0u : n1) + (f2 ? 0u : n2) + (f3 ? 0u : n3);
                             const uint32_t totl = (n0 + n1) + (n2 + n3) - totn;
-                            if (STATS) { ncuttest += in0 ? (set_size - next < 4u ? set_size - next : 4u) : 0u; ncuthit += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u) + (hit2 ? 1u : 0u) + (hit3 ? 1u : 0u); }
+                            if (STATS && !K1_EXP_RUNS_ON) { ncuttest += in0 ? (set_size - next < 4u ? set_size - next : 4u) : 0u; ncuthit += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u) + (hit2 ? 1u : 0u) + (hit3 ? 1u : 0u); }
                             const uint32_t rhi = ray0 << SH;                            // item: ray | node index, or ray | first * 2 | count - 1 of a leaf
                             if (nq + totn <= (uint32_t)K1_NQ && lq + totl <= (uint32_t)K1_LQ) {
 #define VKR_CUT_PUSH(H, F, M, N, E)                                                                                 \
@@ -1471,6 +1476,20 @@ __global__ __launch_bounds__(K1Q_BLOCK) __attribute__((amdgpu_waves_per_eu(K1_WA
                 const uint32_t it0 = act0 ? s_nq[VKR_BOUND(nq + (uint32_t)lane, K1_NQ, 65536)] : 0u;
                 const NodeIn in0 = fetch(it0);
                 VKR_PRIO_LO
+#ifdef VKR_EXP_RUNS   // experiment (STATS build): how coherent a node step's items are -- distinct 128-byte node lines and distinct nodes
+                      // among the step's items, reported in the cut_box_tests / cut_hits slots of the phase dump
+                if (STATS) {
+                    const uint32_t nd = it0 & PMASK;
+                    uint32_t lines = 0, nodes = 0;
+                    for (uint32_t i_ = 0; i_ < n && i_ < 64u; ++i_) {
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)nd, (int)i_);
+                        const unsigned long long ml = __ballot(act0 && (nd >> 1) == (v >> 1)), mn_ = __ballot(act0 && nd == v);
+                        lines += ((uint32_t)__ffsll((long long)ml) - 1u == i_) ? 1u : 0u;
+                        nodes += ((uint32_t)__ffsll((long long)mn_) - 1u == i_) ? 1u : 0u;
+                    }
+                    if (lane == 0) { ncuttest += lines; ncuthit += nodes; }
+                }
+#endif
                 if (K1_STEP > 64u && n > 64u) {                                     // wave-uniform
                     const uint32_t it1 = act1 ? s_nq[nq + 64u + (uint32_t)lane] : 0u;
                     const NodeIn in1 = fetch(it1);
