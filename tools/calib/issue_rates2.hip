@@ -46,6 +46,12 @@ KERNEL(k_mul_legacy, "v_mul_legacy_f32", ", %8")
 KERNEL(k_cvt_pk_f16, "v_cvt_pkrtz_f16_f32", ", %8")
 KERNEL(k_fma_mix, "v_fma_mix_f32", ", %8, %9")
 KERNEL(k_exp_f32, "v_exp_f32", "")
+// round 3: the opcodes of K2's software exp that the first sets did not cover (literal-constant fmas, ldexp, rndne, cvt to int)
+KERNEL(k_fmaak_f32, "v_fmaak_f32", ", %8, 0x3f000001")
+KERNEL(k_fmamk_f32, "v_fmamk_f32", ", 0x3f000001, %8")
+KERNEL(k_ldexp_f32, "v_ldexp_f32", ", 0")
+KERNEL(k_rndne_f32, "v_rndne_f32", "")
+KERNEL(k_cvt_i32_f32, "v_cvt_i32_f32", "")
 
 typedef void (*kfn)(float*, int);
 static void run(const char* name, kfn k, float* sink)
@@ -75,5 +81,6 @@ int main()
     RUN(k_min3_f32); RUN(k_med3_f32); RUN(k_add_u32); RUN(k_and_b32); RUN(k_or_b32); RUN(k_lshlrev_b32); RUN(k_lshl_add_u32);
     RUN(k_bfe_u32); RUN(k_mov_b32); RUN(k_perm_b32); RUN(k_cvt_f32_u32); RUN(k_mad_u32_u24); RUN(k_add3_u32);
     RUN(k_mul_legacy); RUN(k_cvt_pk_f16); RUN(k_fma_mix); RUN(k_exp_f32);
+    RUN(k_fmaak_f32); RUN(k_fmamk_f32); RUN(k_ldexp_f32); RUN(k_rndne_f32); RUN(k_cvt_i32_f32);
     return 0;
 }

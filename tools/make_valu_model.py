@@ -41,7 +41,7 @@ def main():
     census = json.load(open(os.path.join(P, f"{ROUND}_k1_isa_census.json")))
     # static class mix of the loop's opcodes that no SQ_INSTS_VALU_* class counter resolves
     ops = census["loop"]["top_valu_opcodes_all"]
-    resolved = re.compile(r"v_(add|sub|subrev|mul|fma|fmac|mul_legacy|pk_add|pk_mul|pk_fma)_f32|v_cvt|v_(rcp|rsq|sqrt|exp|log|sin|cos)")
+    resolved = re.compile(r"v_(add|sub|subrev|mul|fma|fmac|fmaak|fmamk|mul_legacy|pk_add|pk_mul|pk_fma)_f32|v_cvt|v_(rcp|rsq|sqrt|exp|log|sin|cos)")
     un = {o: n for o, n in ops.items() if not resolved.match(o)}
     un_cost = sum(n * {"fast": FAST, "slow": SLOW, "trans": TRANS}[census["loop"]["op_class"][o]] for o, n in un.items()) / sum(un.values())
     # K2 (k_atrous_tile) has no inner loop worth isolating: the whole kernel's static mix prices its unresolved instructions
@@ -49,7 +49,7 @@ def main():
     un2 = {o: n for o, n in census2["top_valu_opcodes_all"].items() if not resolved.match(o)}
     un2_cost = sum(n * {"fast": FAST, "slow": SLOW, "trans": TRANS}[census2["op_class"][o]] for o, n in un2.items()) / sum(un2.values())
     model = {"_doc": __doc__.strip().split("\n\n")[1].replace("\n", " "),
-             "class_cycles": {"fast": FAST, "slow": SLOW, "trans": TRANS, "source": "profiles/r2_issue_rates.jsonl, profiles/r2_issue_rates2.jsonl"},
+             "class_cycles": {"fast": FAST, "slow": SLOW, "trans": TRANS, "source": "profiles/r2_issue_rates.jsonl, profiles/r2_issue_rates2.jsonl, profiles/r3_issue_rates3.jsonl"},
              "unresolved_opcodes_static_cost": round(un_cost, 3), "census": f"profiles/{ROUND}_k1_isa_census.json",
              "source_fingerprint": kernel_source_fingerprint(),
              "source_fingerprint_note": "sha256 over the kernel sources these counters were measured on (vulkanrenderer_amd/fingerprint.py); bench.py and "
